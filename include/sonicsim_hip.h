@@ -1,0 +1,137 @@
+/* sonicsim_hip.h -- C-ABI of libsonicsim_hip.so (MI355X / gfx950 moving-source audio renderer).
+ *
+ * The reference (JusperLee/SonicSim) has no FFI layer: its boundary for this path is the set of
+ * module-level Python functions that SonicSim-SonicSet/SonicSet.py imports (SonicSet.py:16-21).
+ * Every entry point below names the reference function (file:line, relative to the reference
+ * repository root) whose arithmetic it replaces; the ctypes stubs a maintainer adds on the
+ * reference side are shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain C: pointers + sizes only, no torch / C++ types.
+ *   - every function returns 0 on success or a negative SS_E* code; ss_last_error() returns a
+ *     thread-local human-readable message.  No exception crosses the boundary.
+ *   - flags bit 0 (SS_FLAG_DEVICE_PTR): data pointers are DEVICE pointers (zero copy; work is
+ *     enqueued on `stream` and the call does not synchronise).  Otherwise they are HOST pointers:
+ *     the library stages H2D/D2H itself and returns after the result is in host memory.
+ *   - `stream` is a hipStream_t (NULL = the default stream).
+ *   - the caller owns every buffer; inputs are never modified unless documented.
+ *   - layouts are C-contiguous float32 unless stated: x[T], rirs[P][C][L], y[C][T].
+ */
+#ifndef SONICSIM_HIP_H
+#define SONICSIM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SS_VERSION 100 /* 0.1.0 */
+
+#define SS_OK 0
+#define SS_EINVAL (-1)   /* bad argument (shape, range, NULL) -> Python ValueError  */
+#define SS_EHIP (-2)     /* HIP runtime error                  -> Python RuntimeError */
+#define SS_ENOMEM (-3)   /* device/host allocation failed      -> Python MemoryError  */
+#define SS_ENODEV (-4)   /* no usable GPU                      -> Python RuntimeError */
+
+#define SS_FLAG_DEVICE_PTR 0x1u   /* data pointers are device pointers                       */
+#define SS_FLAG_PATH_OS 0x10u     /* force the overlap-save (transform) engine               */
+#define SS_FLAG_PATH_DIRECT 0x20u /* force the direct-form engine (exact fp32 fmaf chain)    */
+#define SS_FLAG_LAYOUT_TC 0x100u  /* audio is [T][C] instead of [C][T] (loudness / mix calls) */
+
+int ss_version(void);
+const char* ss_last_error(void);
+
+/* Lazy: every entry point initialises the current HIP device on first use.  ss_init pins the
+ * device explicitly (device < 0 = keep the current one).  Importing the Python shim never calls
+ * this (SonicSet.py:154 uses the 'spawn' start method; workers re-import modules). */
+int ss_init(int device);
+int ss_shutdown(void);
+
+/* ---- row V: SonicSim-SonicSet/SonicSim_moving.py:63-96  convolve_moving_receiver -------------
+ * y[c,t] = (1-w[t]) * (x * rirs[idx[t],c])[t] + w[t] * (x * rirs[idx[t]+1,c])[t],  0 <= t < T
+ * (causal, zero initial state, tail dropped -- the [..., :audio_len] crop at :86).
+ * idx[T] int64 with 0 <= idx[t] <= P-2 (arbitrary, not necessarily monotone -- :89-94 is a pure
+ * gather); w[T] float32.  Replaces oaconvolve (:86) + fancy-index gather (:89-90) + lerp (:94). */
+int ss_convolve_moving_f32(const float* x, int64_t T, const float* rirs, int32_t P, int32_t C, int32_t L,
+                           const int64_t* idx, const float* w, float* y, uint32_t flags, void* stream);
+
+/* ---- rows I+V fused: SonicSim_moving.py:42-45 + :63-96 ---------------------------------------
+ * Fast path of interpolate_moving_audio (SonicSim_moving.py:98-125).  The host keeps only the O(P)
+ * half of setup_dynamic_interp (:32-39, the NumPy-RNG-coupled segment lengths n_k); the O(T)
+ * expansion idx = repeat(arange(P-1), n_k), w = concat(linspace(0,1,n_k,endpoint=False)) (:42-45)
+ * is implicit in the kernel epilogue (bit-exact float32 ramp).
+ * seg_len[P-1] is ALWAYS a host pointer; seg_len[k] >= 0, sum == T. */
+int ss_convolve_moving_seg_f32(const float* x, int64_t T, const float* rirs, int32_t P, int32_t C, int32_t L,
+                               const int64_t* seg_len, float* y, uint32_t flags, void* stream);
+
+/* ---- row F: SonicSim_moving.py:47-61  convolve_fixed_receiver --------------------------------
+ * y[c,t] = (x * h[c])[t], 0 <= t < T.   h[C][L]. Replaces scipy.signal.fftconvolve(...)[:, :T]. */
+int ss_convolve_fixed_f32(const float* x, int64_t T, const float* h, int32_t C, int32_t L, float* y,
+                          uint32_t flags, void* stream);
+
+/* ---- row R: SonicSim-SonicSet/SonicSim_rir.py:668-721 render_ir, :611-666 create_custom_arrayir,
+ *      :724-791 render_rir_parallel  (output contract only; the Habitat/RLR path tracer is an
+ *      external closed-source library -> PARITY UNPINNED) ------------------------
+ * Synthetic RIR bank, generated on the device:
+ *   bank[p,c,t] = dgain[p,c]*[t==delay[p,c]] + tail_gain*exp(-6.91 t/(rt60*fs))*n_p[c,t]*[t>delay[p,c]]
+ *   n_0 = g_0, n_p = rho*n_{p-1} + sqrt(1-rho^2)*g_p, g = counter-hash Box-Muller normal(seed,p,c,t)
+ * delay/dgain are HOST pointers ([P][C], O(P*C) metadata).  bank[P][C][L] follows flags bit 0. */
+typedef struct SsRirParams {
+    int32_t P, C, L;
+    float fs;          /* sample rate (SonicSim_rir.py:178: 16000)           */
+    float rt60;        /* seconds                                              */
+    float tail_gain;   /* diffuse tail level relative to a unit direct path    */
+    float rho;         /* AR(1) correlation of the tail across adjacent positions */
+    uint32_t seed;
+    const int32_t* delay; /* [P][C] direct-path delay in samples (host)      */
+    const float* dgain;   /* [P][C] direct-path gain (host)                  */
+} SsRirParams;
+int ss_rir_bank_synth_f32(const SsRirParams* prm, float* bank, uint32_t flags, void* stream);
+
+/* ---- row G: SonicSim-SonicSet/SonicSim_audio.py:398  ir_output /= ir_output.abs().max() -------
+ * In-place global peak normalisation (IEEE float32 division, bit-exact with the reference's
+ * elementwise true division).  peak_out (HOST pointer, may be NULL) receives the peak; asking for
+ * it synchronises the stream.  A zero peak leaves the data unchanged and returns SS_OK. */
+int ss_peak_normalize_f32(float* data, int64_t n, float* peak_out, uint32_t flags, void* stream);
+
+/* ---- row M: separation/look2hear/datas/movingdatamodule.py:29-32 compute_mch_rms_dB ----------
+ * out_db[i] = 10*log10(max(1e-20, mean(x_i^2))) over ALL n elements of each of `count` equally
+ * sized arrays x[count][n].  out_db is a HOST pointer (synchronises). */
+int ss_rms_db_f32(const float* x, int64_t n, int32_t count, double* out_db, uint32_t flags, void* stream);
+
+/* ---- row M: movingdatamodule.py:105-124 (twin at :205-224) SIR/SNR mix -----------------------
+ * speakers[S][n] (interferers 1..S-1 are scaled IN PLACE like :113), noises[N][n],
+ * sirs[S-1] (host), snr (dB).  mix[n] = sum_s speakers[s] + g_n * sum_k noises[k] with
+ *   g_i = 10^(min(E(spk0) - E(spk_i) - sir_i, 40)/20),  g_n = 10^(min(E(speech) - E(noise) - snr, 40)/20).
+ * gains_out (host, may be NULL) receives [g_1..g_{S-1}, g_n].  No host synchronisation unless
+ * gains_out != NULL or host-pointer mode. */
+int ss_mix_f32(float* speakers, int32_t S, const float* noises, int32_t N, int64_t n, const float* sirs,
+               float snr, float* mix, float* gains_out, uint32_t flags, void* stream);
+
+/* ---- row U: SonicSim-SonicSet/SonicSim_audio.py:68-81 lufs_norm (pyloudnorm.Meter) -----------
+ * BS.1770-4 K-weighted mean-square per gating block:  z[c][j] = sum_{t in [lo_j,hi_j)} k(x_c)[t]^2 / norm
+ * where k() is the two-biquad K-weighting cascade (float64 state, coefficients coef[2][6] =
+ * {b0,b1,b2,a0,a1,a2} per stage, HOST pointer), block bounds lo/hi [nblocks] int64 (HOST).
+ * audio is [C][T] (or [T][C] with SS_FLAG_LAYOUT_TC).  z_out[C][nblocks] float64 is a HOST pointer
+ * (synchronises).  The gating arithmetic (O(blocks)) stays on the host like segment lengths do. */
+int ss_kweighted_block_power_f32(const float* audio, int64_t T, int32_t C, const double* coef,
+                                 const int64_t* lo, const int64_t* hi, int32_t nblocks, double norm,
+                                 double* z_out, uint32_t flags, void* stream);
+
+/* out[i] = gain * in[i]  (pyloudnorm.normalize.loudness, called at SonicSim_audio.py:77);
+ * sums_out (host, may be NULL): {sum(out), sum(in)} in float64 for the gain = n/d of :78-79. */
+int ss_scale_f32(const float* in, float* out, int64_t n, float gain, double* sums_out, uint32_t flags,
+                 void* stream);
+
+/* ---- measurement hooks (bench.py): HIP-event timing of the dominant kernels on their own stream.
+ * kind 0 = overlap-save render kernel (one parity pass = one launch), 1 = input-spectra kernel,
+ * 2 = direct-form kernel.  ss_prof_read synchronises, then returns count and total milliseconds
+ * accumulated since the last ss_prof_enable(1). */
+int ss_prof_enable(int on);
+int ss_prof_read(int kind, int64_t* launches, double* total_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SONICSIM_HIP_H */

@@ -1,0 +1,121 @@
+// plan.h -- host-side task planning for the row-stationary render (plain C++, shared by the HIP
+// library and the CPU workgroup emulator used in tests).
+//
+// Work decomposition: filter row r contributes to output sample t iff idx[t] == r (start filter)
+// or idx[t]+1 == r (end filter) -- SonicSim_moving.py:89-90.  From the per-block min/max of idx
+// (a fine grid of DTILE samples) we derive, for every row, the set of output blocks it touches,
+// split it into runs of consecutive blocks of at most JMAX, and emit one Task per (run, channel).
+// Rows are separated by parity: every sample has exactly one even and one odd responsible row, so
+// the even pass STORES and the odd pass ADDS -- deterministic, no atomics, no zero fill.
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "tvfir_core.h"
+
+namespace ss {
+
+struct Plan {
+    std::vector<Task> tasks[2];   // [parity]
+    int64_t pairs = 0;            // number of (row, block) pairs
+};
+
+// per-fine-block (DTILE grid) min/max of idx for the implicit (segment) schedule
+inline void seg_minmax(const std::vector<int64_t>& seg_start /*[P], last == T*/, int64_t T,
+                       std::vector<int32_t>& bmin, std::vector<int32_t>& bmax) {
+    const int64_t nb = (T + DTILE - 1) / DTILE;
+    bmin.resize(nb);
+    bmax.resize(nb);
+    const int P = (int)seg_start.size();
+    // segment of sample t: last k in [0, P-2] with seg_start[k] <= t
+    auto seg_of = [&](int64_t t) {
+        int lo = 0, hi = P - 2;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (seg_start[mid] <= t) lo = mid; else hi = mid - 1;
+        }
+        return lo;
+    };
+    for (int64_t b = 0; b < nb; ++b) {
+        const int64_t t0 = b * DTILE, t1 = std::min<int64_t>(T, t0 + DTILE) - 1;
+        bmin[b] = seg_of(t0);
+        bmax[b] = seg_of(t1);
+    }
+}
+
+// Build tasks.  `fine_per_block` = B/DTILE for the overlap-save engine, 1 for the direct engine.
+inline void build_plan(const std::vector<int32_t>& bmin, const std::vector<int32_t>& bmax, int P, int C,
+                       int fine_per_block, int jmax, Plan& plan) {
+    plan.tasks[0].clear();
+    plan.tasks[1].clear();
+    plan.pairs = 0;
+    const int64_t nfine = (int64_t)bmin.size();
+    const int64_t nblk = (nfine + fine_per_block - 1) / fine_per_block;
+    std::vector<std::vector<int32_t>> rows(P);
+    for (int64_t j = 0; j < nblk; ++j) {
+        int32_t lo = INT32_MAX, hi = INT32_MIN;
+        for (int f = 0; f < fine_per_block; ++f) {
+            const int64_t fb = j * fine_per_block + f;
+            if (fb < nfine) { lo = std::min(lo, bmin[fb]); hi = std::max(hi, bmax[fb]); }
+        }
+        for (int32_t r = lo; r <= hi + 1 && r < P; ++r) rows[r].push_back((int32_t)j);
+    }
+    for (int r = 0; r < P; ++r) {
+        const auto& bl = rows[r];
+        plan.pairs += (int64_t)bl.size();
+        size_t i = 0;
+        while (i < bl.size()) {
+            size_t e = i + 1;
+            while (e < bl.size() && bl[e] == bl[e - 1] + 1 && (int)(e - i) < jmax) ++e;
+            for (int c = 0; c < C; ++c) {
+                Task t;
+                t.row = r;
+                t.chan = c;
+                t.j0 = bl[i];
+                t.nj = (int32_t)(e - i);
+                plan.tasks[r & 1].push_back(t);
+            }
+            i = e;
+        }
+    }
+}
+
+// fixed receiver: one row, every block, store pass only
+inline void build_plan_fixed(int64_t T, int C, int block, int jmax, Plan& plan) {
+    plan.tasks[0].clear();
+    plan.tasks[1].clear();
+    const int64_t nblk = (T + block - 1) / block;
+    plan.pairs = nblk;
+    for (int64_t j = 0; j < nblk; j += jmax) {
+        for (int c = 0; c < C; ++c) {
+            Task t;
+            t.row = 0;
+            t.chan = c;
+            t.j0 = (int32_t)j;
+            t.nj = (int32_t)std::min<int64_t>(jmax, nblk - j);
+            plan.tasks[0].push_back(t);
+        }
+    }
+}
+
+// constant tables in double precision (see tvfir_core.h layout)
+inline void build_consts(std::vector<c32>& tab) {
+    tab.assign(CONST_C32, c32{0.f, 0.f});
+    const double PI = 3.14159265358979323846264338327950288;
+    auto W = [&](double num, double den) {   // exp(-2 pi i num/den)
+        const double a = -2.0 * PI * num / den;
+        return c32{(float)std::cos(a), (float)std::sin(a)};
+    };
+    for (int k = 1; k < 8; ++k)
+        for (int t = 0; t < 256; ++t) tab[TW1_OFF + (k - 1) * 256 + t] = W((double)((t * k) % 2048), 2048.0);
+    for (int k = 1; k < 8; ++k)
+        for (int m = 0; m < 32; ++m) tab[TW2_OFF + (k - 1) * 32 + m] = W((double)((m * k) % 256), 256.0);
+    for (int k = 1; k < 8; ++k)
+        for (int n = 0; n < 4; ++n) tab[TW3_OFF + (k - 1) * 4 + n] = W((double)((n * k) % 32), 32.0);
+    for (int n = 0; n < 2048; ++n) tab[TWIST_OFF + n] = W((double)n, 8192.0);   // exp(-i pi n / 4096)
+}
+
+}  // namespace ss

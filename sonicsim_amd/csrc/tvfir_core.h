@@ -1,0 +1,450 @@
+// tvfir_core.h -- time-varying multichannel FIR (moving-source render) kernel bodies.
+//
+// One source, two compilations:
+//   * hipcc --offload-arch=gfx950 : the kernel bodies run as HIP workgroups (256 threads = 4 wave64)
+//   * g++ (tests/emul)            : the SAME bodies run under a std::thread/std::barrier
+//                                   "workgroup emulator" so the index gymnastics can be verified on
+//                                   a machine without a GPU.  The emulator is test infrastructure.
+//
+// Replaces the hot loops of SonicSim-SonicSet/SonicSim_moving.py:86-94 (oaconvolve with EVERY
+// position + fancy-index gather + lerp) by a row-stationary, uniformly partitioned overlap-save:
+//   y[c,t] = sum_r coef_r(t) * (x * h[r,c])[t],  coef_r(t) = (1-w[t]) [idx[t]==r] + w[t] [idx[t]+1==r]
+// Each workgroup owns ONE filter row (r,c) (read from HBM exactly once, coalesced) and up to JMAX
+// output blocks of B samples; partition spectra H_p are produced on the fly in LDS/registers and
+// multiplied with the shared input spectra X_m (L2 resident); accumulators live in VGPRs.
+//
+// Transform: "right-angle" (odd-frequency) DFT.  A real 2B window a[] is folded to
+//   z[n] = (a[n] - i a[n+B]) * exp(-i pi n / 2B),  n < B
+// and transformed by ONE B-point complex FFT.  All B bins are ordinary complex numbers (no
+// DC/Nyquist special case, no real-FFT split pass); bin products realise the negacyclic convolution
+// whose samples [B,2B) equal the linear convolution with a B-tap partition (overlap-save valid part).
+//
+// FFT: B = 2048 = 8*8*8*4, decimation in frequency, 8 points per thread, 3 LDS exchanges.
+// Forward leaves bins in a permuted "slot" order (thread tid, register r); the inverse is the
+// transposed flow graph and consumes exactly that order, so no reordering pass exists anywhere.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define SS_HD __host__ __device__ __forceinline__
+#else
+#define SS_HD inline
+#endif
+
+namespace ss {
+
+struct c32 {
+    float x, y;
+};
+
+constexpr int B = 2048;   // output block = filter partition = complex FFT length
+constexpr int NT = 256;   // threads per workgroup
+constexpr int JMAX = 6;   // output blocks accumulated in registers per task
+constexpr int DTILE = 1024;  // direct-form output tile
+constexpr int DCHUNK = 256;  // direct-form tap chunk
+
+// constant table layout (c32 units), built on the host in double precision (ss_build_consts)
+constexpr int TW1_OFF = 0;       // [7][256]  W_2048^(t*k1),   k1 = 1..7
+constexpr int TW2_OFF = 1792;    // [7][32]   W_256^(m2*k2),   k2 = 1..7
+constexpr int TW3_OFF = 2016;    // [7][4]    W_32^(n4*k3),    k3 = 1..7
+constexpr int TWIST_OFF = 2048;  // [2048]    exp(-i pi n / 4096)
+constexpr int CONST_C32 = 4096;
+constexpr int EX_C32 = 2304;     // one padded exchange buffer
+constexpr int LDS_C32 = CONST_C32 + 2 * EX_C32;   // 8704 c32 = 69632 bytes
+
+struct Task {
+    int32_t row;    // filter row index r (position); 0 for the fixed-receiver path
+    int32_t chan;   // channel c
+    int32_t j0;     // first output block (OS: B grid, direct: DTILE grid)
+    int32_t nj;     // number of blocks (1..JMAX; direct: 1)
+};
+
+enum CoefMode : int32_t { COEF_FIXED = 0, COEF_SEG = 1, COEF_EXPLICIT = 2 };
+
+struct RenderParams {
+    const float* x;          // [T]
+    int64_t T;
+    const float* bank;       // [P][C][L]
+    int32_t P, C, L;
+    int32_t NP;              // ceil(L / B)
+    const c32* Xs;           // [M][B] input spectra in slot order
+    int32_t M;               // ceil(T / B)
+    const c32* consts;       // [CONST_C32]
+    const Task* tasks;
+    int32_t mode;            // CoefMode
+    int32_t accumulate;      // 0: y = contribution (even rows), 1: y += contribution (odd rows)
+    const int64_t* seg_start;  // [P]  COEF_SEG: segment k covers [seg_start[k], seg_start[k+1]); seg_start[P-1] == T
+    const int64_t* idx;      // [T]  COEF_EXPLICIT
+    const float* w;          // [T]  COEF_EXPLICIT
+    float* y;                // [C][T]
+};
+
+// ---------------------------------------------------------------------------------------------
+// complex helpers
+SS_HD c32 mk(float x, float y) { c32 r; r.x = x; r.y = y; return r; }
+SS_HD c32 cadd(c32 a, c32 b) { return mk(a.x + b.x, a.y + b.y); }
+SS_HD c32 csub(c32 a, c32 b) { return mk(a.x - b.x, a.y - b.y); }
+SS_HD c32 cmul(c32 a, c32 b) { return mk(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+SS_HD c32 cmulc(c32 a, c32 b) { return mk(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }  // a * conj(b)
+template <bool INV> SS_HD c32 ctw(c32 a, c32 w) { return INV ? cmulc(a, w) : cmul(a, w); }
+// multiply by -i (forward) / +i (inverse)
+template <bool INV> SS_HD c32 rot90(c32 a) { return INV ? mk(-a.y, a.x) : mk(a.y, -a.x); }
+
+// 4-point DFT (forward: W4 = -i).  in/out natural order.
+template <bool INV> SS_HD void dft4(c32& a0, c32& a1, c32& a2, c32& a3) {
+    c32 c0 = cadd(a0, a2), c1 = csub(a0, a2), c2 = cadd(a1, a3), c3 = rot90<INV>(csub(a1, a3));
+    a0 = cadd(c0, c2);
+    a2 = csub(c0, c2);
+    a1 = cadd(c1, c3);
+    a3 = csub(c1, c3);
+}
+
+// 8-point DFT, natural in -> natural out (register renaming is free).
+template <bool INV> SS_HD void dft8(c32* v) {
+    const float s = 0.70710678118654752440f;
+    c32 a0 = cadd(v[0], v[4]), a4 = csub(v[0], v[4]);
+    c32 a1 = cadd(v[1], v[5]), a5 = csub(v[1], v[5]);
+    c32 a2 = cadd(v[2], v[6]), a6 = csub(v[2], v[6]);
+    c32 a3 = cadd(v[3], v[7]), a7 = csub(v[3], v[7]);
+    // odd branch twiddles W8^1, W8^2, W8^3 (conjugated for the inverse)
+    if (INV) {
+        a5 = mk((a5.x - a5.y) * s, (a5.x + a5.y) * s);     // * (1+i)/sqrt2
+        a7 = mk((-a7.x - a7.y) * s, (a7.x - a7.y) * s);    // * (-1+i)/sqrt2
+    } else {
+        a5 = mk((a5.x + a5.y) * s, (a5.y - a5.x) * s);     // * (1-i)/sqrt2
+        a7 = mk((a7.y - a7.x) * s, (-a7.x - a7.y) * s);    // * (-1-i)/sqrt2
+    }
+    a6 = rot90<INV>(a6);
+    dft4<INV>(a0, a1, a2, a3);   // X0 X2 X4 X6
+    dft4<INV>(a4, a5, a6, a7);   // X1 X3 X5 X7
+    v[0] = a0; v[2] = a1; v[4] = a2; v[6] = a3;
+    v[1] = a4; v[3] = a5; v[5] = a6; v[7] = a7;
+}
+
+// ---------------------------------------------------------------------------------------------
+// LDS view of one workgroup
+struct LdsView {
+    c32* base;
+    SS_HD const c32* tw1() const { return base + TW1_OFF; }
+    SS_HD const c32* tw2() const { return base + TW2_OFF; }
+    SS_HD const c32* tw3() const { return base + TW3_OFF; }
+    SS_HD const c32* twist() const { return base + TWIST_OFF; }
+    // the two exchange buffers swap roles every transform (see hazard note in fft_fwd)
+    SS_HD c32* exA(int par) const { return base + CONST_C32 + (par ? EX_C32 : 0); }
+    SS_HD c32* exB(int par) const { return base + CONST_C32 + (par ? 0 : EX_C32); }
+};
+
+// Forward B-point FFT.  In: v[n1] = z[n1*256 + tid].  Out: v[r] = Z[bin(tid,r)] ("slot order"):
+//   G = tid + 256*(r>>2) = k1*64 + k2*8 + k3,  k4 = r&3,  bin = k1 + 8*k2 + 64*k3 + 512*k4.
+// Buffer use is A,B,A with (A,B) swapped every call (par ^= 1): a transform's first write goes to
+// the buffer whose last read is separated from it by the previous transform's final barrier, so
+// three barriers per transform are sufficient.
+template <class Env> SS_HD void fft_fwd(Env& env, const LdsView& l, c32* v, int& par) {
+    const int tid = env.tid();
+    c32* A = l.exA(par);
+    c32* Bf = l.exB(par);
+    par ^= 1;
+    // pass 1: radix-8 over n1 (stride 256), twiddle W_2048^(tid*k1)
+    dft8<false>(v);
+    A[tid] = v[0];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) A[k * 256 + tid] = cmul(v[k], l.tw1()[(k - 1) * 256 + tid]);
+    env.barrier();
+    // pass 2: thread (k1 = tid>>5, m2 = tid&31): radix-8 over n2 (stride 32), twiddle W_256^(m2*k2)
+    {
+        const int k1 = tid >> 5, m2 = tid & 31;
+#pragma unroll
+        for (int n = 0; n < 8; ++n) v[n] = A[k1 * 256 + n * 32 + m2];
+        dft8<false>(v);
+        Bf[(k1 * 8) * 36 + m2] = v[0];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) Bf[(k1 * 8 + k) * 36 + m2] = cmul(v[k], l.tw2()[(k - 1) * 32 + m2]);
+    }
+    env.barrier();
+    // pass 3: thread (g = tid>>2 = k1*8+k2, n4 = tid&3): radix-8 over n3 (stride 4), twiddle W_32^(n4*k3)
+    {
+        const int g = tid >> 2, n4 = tid & 3;
+#pragma unroll
+        for (int n = 0; n < 8; ++n) v[n] = Bf[g * 36 + n * 4 + n4];
+        dft8<false>(v);
+        A[(g * 9) * 4 + n4] = v[0];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) A[(g * 9 + k) * 4 + n4] = cmul(v[k], l.tw3()[(k - 1) * 4 + n4]);
+    }
+    env.barrier();
+    // pass 4: two radix-4 over n4 for groups G0 = tid, G1 = tid + 256  (G = g*8 + k3)
+    {
+        const int g0 = tid >> 3, k3 = tid & 7;
+        const c32* p0 = A + (g0 * 9 + k3) * 4;
+        const c32* p1 = A + ((g0 + 32) * 9 + k3) * 4;
+#pragma unroll
+        for (int n = 0; n < 4; ++n) { v[n] = p0[n]; v[4 + n] = p1[n]; }
+        dft4<false>(v[0], v[1], v[2], v[3]);
+        dft4<false>(v[4], v[5], v[6], v[7]);
+    }
+}
+
+// Inverse (unnormalised, conjugate twiddles): transposed flow graph of fft_fwd.
+// In: slot order.  Out: v[n1] = z[n1*256 + tid] * B.
+template <class Env> SS_HD void fft_inv(Env& env, const LdsView& l, c32* v, int& par) {
+    const int tid = env.tid();
+    c32* A = l.exA(par);
+    c32* Bf = l.exB(par);
+    par ^= 1;
+    {
+        const int g0 = tid >> 3, k3 = tid & 7;
+        dft4<true>(v[0], v[1], v[2], v[3]);
+        dft4<true>(v[4], v[5], v[6], v[7]);
+        c32* p0 = A + (g0 * 9 + k3) * 4;
+        c32* p1 = A + ((g0 + 32) * 9 + k3) * 4;
+#pragma unroll
+        for (int n = 0; n < 4; ++n) { p0[n] = v[n]; p1[n] = v[4 + n]; }
+    }
+    env.barrier();
+    {
+        const int g = tid >> 2, n4 = tid & 3;
+        v[0] = A[(g * 9) * 4 + n4];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) v[k] = cmulc(A[(g * 9 + k) * 4 + n4], l.tw3()[(k - 1) * 4 + n4]);
+        dft8<true>(v);
+#pragma unroll
+        for (int n = 0; n < 8; ++n) Bf[g * 36 + n * 4 + n4] = v[n];
+    }
+    env.barrier();
+    {
+        const int k1 = tid >> 5, m2 = tid & 31;
+        v[0] = Bf[(k1 * 8) * 36 + m2];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) v[k] = cmulc(Bf[(k1 * 8 + k) * 36 + m2], l.tw2()[(k - 1) * 32 + m2]);
+        dft8<true>(v);
+#pragma unroll
+        for (int n = 0; n < 8; ++n) A[k1 * 256 + n * 32 + m2] = v[n];
+    }
+    env.barrier();
+    {
+        v[0] = A[tid];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) v[k] = cmulc(A[k * 256 + tid], l.tw1()[(k - 1) * 256 + tid]);
+        dft8<true>(v);
+    }
+}
+
+template <class Env> SS_HD void load_consts(Env& env, const LdsView& l, const c32* consts) {
+    const int tid = env.tid();
+    for (int i = tid; i < CONST_C32; i += NT) l.base[i] = consts[i];
+    env.barrier();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Per-sample interpolation coefficient of filter row r at output sample t (rows I/V of SURVEY 8a).
+// Returns false when row r is not one of the two rows responsible for t.
+//   COEF_SEG reproduces np.linspace(0,1,n,endpoint=False).astype(float32) bit-exactly:
+//   w = float(double(i) * (1.0/double(n)))  (SonicSim_moving.py:43-45), start coef = 1.0f - w (:94).
+struct RowCoef {
+    int32_t mode, row;
+    int64_t a0, a1, a2;      // COEF_SEG: [a0,a1) row is END filter of segment row-1; [a1,a2) START of segment row
+    double inv0, inv1;
+    const int64_t* idx;
+    const float* w;
+};
+
+SS_HD RowCoef make_rowcoef(const RenderParams& prm, int row) {
+    RowCoef rc;
+    rc.mode = prm.mode;
+    rc.row = row;
+    rc.idx = prm.idx;
+    rc.w = prm.w;
+    rc.a0 = rc.a1 = rc.a2 = 0;
+    rc.inv0 = rc.inv1 = 0.0;
+    if (prm.mode == COEF_SEG) {
+        rc.a1 = prm.seg_start[row];
+        rc.a0 = row > 0 ? prm.seg_start[row - 1] : rc.a1;
+        rc.a2 = row < prm.P - 1 ? prm.seg_start[row + 1] : rc.a1;
+        if (rc.a1 > rc.a0) rc.inv0 = 1.0 / (double)(rc.a1 - rc.a0);
+        if (rc.a2 > rc.a1) rc.inv1 = 1.0 / (double)(rc.a2 - rc.a1);
+    }
+    return rc;
+}
+
+SS_HD bool row_coef(const RowCoef& rc, int64_t t, float& coef) {
+    if (rc.mode == COEF_FIXED) { coef = 1.0f; return true; }
+    if (rc.mode == COEF_SEG) {
+        if (t >= rc.a1) {
+            if (t >= rc.a2) return false;
+            const float wv = (float)((double)(t - rc.a1) * rc.inv1);
+            coef = 1.0f - wv;
+            return true;
+        }
+        if (t < rc.a0) return false;
+        coef = (float)((double)(t - rc.a0) * rc.inv0);
+        return true;
+    }
+    const int64_t k = rc.idx[t];
+    if (k == rc.row) { coef = 1.0f - rc.w[t]; return true; }
+    if (k + 1 == rc.row) { coef = rc.w[t]; return true; }
+    return false;
+}
+
+SS_HD void emit(const RenderParams& prm, const RowCoef& rc, int chan, int64_t t, float val) {
+    float coef;
+    if (t < prm.T && row_coef(rc, t, coef)) {
+        float* yp = prm.y + (int64_t)chan * prm.T + t;
+        const float contrib = coef * val;
+        if (prm.accumulate) *yp = *yp + contrib; else *yp = contrib;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Kernel body 1: input spectra.  One workgroup per window m (0 <= m < M):
+//   window m = x[(m-1)B, (m+1)B), zero outside [0,T);  Xs[m][slot] in the layout
+//   c32 index ((r>>1)*256 + tid)*2 + (r&1)  (so the MAC loop reads 16 B per lane, lane-contiguous).
+template <class Env> SS_HD void xspec_body(Env& env, const float* x, int64_t T, const c32* consts, c32* Xs, int m) {
+    LdsView l; l.base = env.lds();
+    load_consts(env, l, consts);
+    const int tid = env.tid();
+    c32 v[8];
+#pragma unroll
+    for (int n1 = 0; n1 < 8; ++n1) {
+        const int n = n1 * 256 + tid;
+        const int64_t tlo = (int64_t)(m - 1) * B + n, thi = (int64_t)m * B + n;
+        const float lo = (tlo >= 0 && tlo < T) ? x[tlo] : 0.0f;
+        const float hi = (thi < T) ? x[thi] : 0.0f;
+        const c32 tw = l.twist()[n];
+        v[n1] = mk(lo * tw.x + hi * tw.y, lo * tw.y - hi * tw.x);   // (lo - i hi) * tw
+    }
+    int par = 0;
+    fft_fwd(env, l, v, par);
+    c32* out = Xs + (int64_t)m * B;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        out[(q * 256 + tid) * 2 + 0] = v[2 * q];
+        out[(q * 256 + tid) * 2 + 1] = v[2 * q + 1];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Kernel body 2: row-stationary partitioned overlap-save.  One workgroup per Task.
+template <class Env> SS_HD void os_body(Env& env, const RenderParams& prm, int task_id) {
+    LdsView l; l.base = env.lds();
+    load_consts(env, l, prm.consts);
+    const int tid = env.tid();
+    const Task tk = prm.tasks[task_id];
+    const float* h = prm.bank + ((int64_t)tk.row * prm.C + tk.chan) * prm.L;
+    const int nj = tk.nj, j0 = tk.j0;
+
+    c32 acc[JMAX][8];
+#pragma unroll
+    for (int j = 0; j < JMAX; ++j)
+#pragma unroll
+        for (int r = 0; r < 8; ++r) acc[j][r] = mk(0.0f, 0.0f);
+
+    // partitions p > j0+nj-1 only meet windows before t=0 (all zero): skip them
+    int np_eff = prm.NP;
+    if (np_eff > j0 + nj) np_eff = j0 + nj;
+
+    float hn[8];
+#pragma unroll
+    for (int n1 = 0; n1 < 8; ++n1) {
+        const int n = n1 * 256 + tid;
+        hn[n1] = (n < prm.L) ? h[n] : 0.0f;
+    }
+    int par = 0;
+    for (int p = 0; p < np_eff; ++p) {
+        c32 v[8];
+#pragma unroll
+        for (int n1 = 0; n1 < 8; ++n1) {
+            const c32 tw = l.twist()[n1 * 256 + tid];
+            v[n1] = mk(hn[n1] * tw.x, hn[n1] * tw.y);
+        }
+        // software prefetch of the next partition (HBM latency hides under this partition's FFT+MAC)
+        if (p + 1 < np_eff) {
+#pragma unroll
+            for (int n1 = 0; n1 < 8; ++n1) {
+                const int n = (p + 1) * B + n1 * 256 + tid;
+                hn[n1] = (n < prm.L) ? h[n] : 0.0f;
+            }
+        }
+        fft_fwd(env, l, v, par);
+#pragma unroll
+        for (int j = 0; j < JMAX; ++j) {
+            const int m = j0 + j - p;
+            if (j < nj && m >= 0) {
+                const c32* Xm = prm.Xs + (int64_t)m * B;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const c32 xa = Xm[(q * 256 + tid) * 2 + 0];
+                    const c32 xb = Xm[(q * 256 + tid) * 2 + 1];
+                    acc[j][2 * q] = cadd(acc[j][2 * q], cmul(xa, v[2 * q]));
+                    acc[j][2 * q + 1] = cadd(acc[j][2 * q + 1], cmul(xb, v[2 * q + 1]));
+                }
+            }
+        }
+    }
+
+    const RowCoef rc = make_rowcoef(prm, tk.row);
+    const float scale = 1.0f / (float)B;
+#pragma unroll
+    for (int j = 0; j < JMAX; ++j) {
+        if (j < nj) {
+            c32 v[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) v[r] = acc[j][r];
+            fft_inv(env, l, v, par);
+#pragma unroll
+            for (int n1 = 0; n1 < 8; ++n1) {
+                const int n = n1 * 256 + tid;
+                const c32 tw = l.twist()[n];
+                const float val = (v[n1].x * tw.y - v[n1].y * tw.x) * scale;   // -Im(z * conj(tw)) / B
+                emit(prm, rc, tk.chan, (int64_t)(j0 + j) * B + n, val);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Kernel body 3: direct-form fallback / cross-check (exact fp32 fmaf chain, no transform).
+// One workgroup per Task{row, chan, tile}; thread owns 4 consecutive outputs of a DTILE tile.
+// LDS: hs[DCHUNK] taps, xs[DTILE + DCHUNK] input window (float).
+template <class Env> SS_HD void direct_body(Env& env, const RenderParams& prm, int task_id) {
+    float* lf = (float*)env.lds();
+    float* hs = lf;                 // [DCHUNK]
+    float* xs = lf + DCHUNK;        // [DTILE + DCHUNK]  xs[i] = x[t0 - tau0 - (DCHUNK-1) + i]
+    const int tid = env.tid();
+    const Task tk = prm.tasks[task_id];
+    const float* h = prm.bank + ((int64_t)tk.row * prm.C + tk.chan) * prm.L;
+    const int64_t t0 = (int64_t)tk.j0 * DTILE;
+    float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
+    // taps beyond t0+DTILE-1 only meet x before 0
+    int64_t lmax = prm.L;
+    if (lmax > t0 + DTILE) lmax = t0 + DTILE;
+    for (int64_t tau0 = 0; tau0 < lmax; tau0 += DCHUNK) {
+        env.barrier();
+        {
+            const int64_t ti = tau0 + tid;
+            hs[tid] = (ti < prm.L) ? h[ti] : 0.0f;
+        }
+        for (int i = tid; i < DTILE + DCHUNK; i += NT) {
+            const int64_t ti = t0 - tau0 - (DCHUNK - 1) + i;
+            xs[i] = (ti >= 0 && ti < prm.T) ? prm.x[ti] : 0.0f;
+        }
+        env.barrier();
+        // output t = t0 + 4*tid + q uses xs[4*tid + q + (DCHUNK-1) - tau']
+        const float* xb = xs + 4 * tid + (DCHUNK - 1);
+#pragma unroll 8
+        for (int u = 0; u < DCHUNK; ++u) {
+            const float hv = hs[u];
+            o0 += hv * xb[0 - u];
+            o1 += hv * xb[1 - u];
+            o2 += hv * xb[2 - u];
+            o3 += hv * xb[3 - u];
+        }
+    }
+    const RowCoef rc = make_rowcoef(prm, tk.row);
+    const int64_t t = t0 + 4 * tid;
+    emit(prm, rc, tk.chan, t + 0, o0);
+    emit(prm, rc, tk.chan, t + 1, o1);
+    emit(prm, rc, tk.chan, t + 2, o2);
+    emit(prm, rc, tk.chan, t + 3, o3);
+}
+
+}  // namespace ss

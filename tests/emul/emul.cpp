@@ -1,0 +1,113 @@
+// emul.cpp -- CPU "workgroup emulator" for the HIP kernel bodies (TEST INFRASTRUCTURE ONLY).
+// Compiles sonicsim_amd/csrc/tvfir_core.h with g++ and runs each 256-thread workgroup as 256
+// std::threads synchronised by a std::barrier, so the exact kernel source (FFT index mapping,
+// LDS exchange layout, task planning, epilogue) is verified on machines without a GPU.
+// Built and used only by tests/test_emul.py.
+#include <barrier>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+#include "../../sonicsim_amd/csrc/plan.h"
+#include "../../sonicsim_amd/csrc/tvfir_core.h"
+
+using namespace ss;
+
+struct HostEnv {
+    int tid_;
+    std::barrier<>* bar;
+    c32* lds_;
+    int tid() const { return tid_; }
+    void barrier() const { bar->arrive_and_wait(); }
+    c32* lds() const { return lds_; }
+};
+
+template <class F> static void launch(int grid, F&& body) {
+    std::vector<c32> lds(LDS_C32);
+    std::barrier<> bar(NT);
+    std::vector<std::thread> th;
+    th.reserve(NT);
+    for (int t = 0; t < NT; ++t) {
+        th.emplace_back([&, t]() {
+            HostEnv env{t, &bar, lds.data()};
+            for (int b = 0; b < grid; ++b) {
+                body(env, b);
+                bar.arrive_and_wait();
+            }
+        });
+    }
+    for (auto& x : th) x.join();
+}
+
+extern "C" {
+
+// forward transform of one 2048-point complex vector; out in slot order (c32 index tid*8 + r)
+int emul_fft_roundtrip(const float* zin /*[2048][2]*/, float* slots /*[2048][2]*/, float* back /*[2048][2]*/) {
+    std::vector<c32> consts;
+    build_consts(consts);
+    launch(1, [&](HostEnv& env, int) {
+        LdsView l; l.base = env.lds();
+        load_consts(env, l, consts.data());
+        c32 v[8];
+        const int tid = env.tid();
+        for (int n1 = 0; n1 < 8; ++n1) v[n1] = mk(zin[2 * (n1 * 256 + tid)], zin[2 * (n1 * 256 + tid) + 1]);
+        int par = 0;
+        fft_fwd(env, l, v, par);
+        for (int r = 0; r < 8; ++r) { slots[2 * (tid * 8 + r)] = v[r].x; slots[2 * (tid * 8 + r) + 1] = v[r].y; }
+        fft_inv(env, l, v, par);
+        for (int n1 = 0; n1 < 8; ++n1) { back[2 * (n1 * 256 + tid)] = v[n1].x; back[2 * (n1 * 256 + tid) + 1] = v[n1].y; }
+    });
+    return 0;
+}
+
+// mode: 0 fixed (P==1), 1 seg (seg_len[P-1]), 2 explicit (idx,w).  path: 0 = overlap-save, 1 = direct
+int emul_render(const float* x, int64_t T, const float* bank, int P, int C, int L, int mode,
+                const int64_t* seg_len, const int64_t* idx, const float* w, float* y, int path, int64_t* ntasks) {
+    std::vector<c32> consts;
+    build_consts(consts);
+    const int M = (int)((T + B - 1) / B);
+    std::vector<c32> Xs((size_t)M * B);
+    if (path == 0) launch(M, [&](HostEnv& env, int m) { xspec_body(env, x, T, consts.data(), Xs.data(), m); });
+
+    Plan plan;
+    std::vector<int64_t> seg_start;
+    std::vector<int32_t> bmin, bmax;
+    const int fine = path == 0 ? B / DTILE : 1;
+    const int jmax = path == 0 ? JMAX : 1;
+    if (mode == 0) {
+        build_plan_fixed(T, C, path == 0 ? B : DTILE, jmax, plan);
+    } else if (mode == 1) {
+        seg_start.resize(P);
+        int64_t s = 0;
+        for (int k = 0; k < P - 1; ++k) { seg_start[k] = s; s += seg_len[k]; }
+        seg_start[P - 1] = s;
+        if (s != T) return -1;
+        seg_minmax(seg_start, T, bmin, bmax);
+        build_plan(bmin, bmax, P, C, fine, jmax, plan);
+    } else {
+        const int64_t nb = (T + DTILE - 1) / DTILE;
+        bmin.assign(nb, INT32_MAX);
+        bmax.assign(nb, INT32_MIN);
+        for (int64_t t = 0; t < T; ++t) {
+            bmin[t / DTILE] = std::min<int32_t>(bmin[t / DTILE], (int32_t)idx[t]);
+            bmax[t / DTILE] = std::max<int32_t>(bmax[t / DTILE], (int32_t)idx[t]);
+        }
+        build_plan(bmin, bmax, P, C, fine, jmax, plan);
+    }
+    RenderParams prm;
+    std::memset(&prm, 0, sizeof(prm));
+    prm.x = x; prm.T = T; prm.bank = bank; prm.P = P; prm.C = C; prm.L = L;
+    prm.NP = (L + B - 1) / B; prm.Xs = Xs.data(); prm.M = M; prm.consts = consts.data();
+    prm.mode = mode; prm.seg_start = seg_start.data(); prm.idx = idx; prm.w = w; prm.y = y;
+    *ntasks = 0;
+    for (int parity = 0; parity < 2; ++parity) {
+        if (plan.tasks[parity].empty()) continue;
+        prm.tasks = plan.tasks[parity].data();
+        prm.accumulate = parity;
+        *ntasks += (int64_t)plan.tasks[parity].size();
+        if (path == 0) launch((int)plan.tasks[parity].size(), [&](HostEnv& env, int b) { os_body(env, prm, b); });
+        else launch((int)plan.tasks[parity].size(), [&](HostEnv& env, int b) { direct_body(env, prm, b); });
+    }
+    return 0;
+}
+}
