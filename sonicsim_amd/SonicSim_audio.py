@@ -1,0 +1,178 @@
+"""Drop-in for the hot-path half of ``SonicSim-SonicSet/SonicSim_audio.py`` (rows G and U).
+
+  generate_rir_combination  SonicSim_audio.py:342-400  (all_pairs :88, clip_all :111, stack :397, peak-norm :398)
+  lufs_norm                 SonicSim_audio.py:68-81    (pyloudnorm Meter + normalize.loudness)
+  get_lufs_norm_audio       SonicSim_audio.py:83-86
+  normalize                 SonicSim_audio.py:49-66
+  fft_conv                  SonicSim_audio.py:17-47    (row X; see note on the reference's odd-length bug)
+
+Loudness (row U) -- the O(T*C) work (K-weighting IIR cascade in float64 + per-gating-block mean
+squares) runs on the GPU (``ss_kweighted_block_power_f32``); the O(blocks) gating arithmetic stays
+on the host.  pyloudnorm is an absent third-party dependency, so its BS.1770-4 algorithm is restated
+(parity unpinned).  pyloudnorm rejects more than 5 channels; that check is kept by
+default and ``allow_many_channels=True`` selects BS.1770 with unit channel weights for mic arrays.
+"""
+from __future__ import annotations
+
+import itertools
+import math
+import typing as T
+
+import numpy as np
+
+from . import ops
+from .SonicSim_rir import render_rir_parallel
+
+G_WEIGHTS = (1.0, 1.0, 1.0, 1.41, 1.41)       # BS.1770 channel weights L R C Ls Rs
+
+
+# ----------------------------------------------------------------------------- row G
+def all_pairs(list1, list2):
+    """SonicSim_audio.py:88-109: cartesian product split back into two parallel lists."""
+    pairs = list(itertools.product(list1, list2))
+    first, second = zip(*pairs)
+    return list(first), list(second)
+
+
+def clip_all(audio_list):
+    """SonicSim_audio.py:111-127: crop every signal to the shortest one."""
+    shortest = min(a.shape[-1] for a in audio_list)
+    return [a[..., :shortest] for a in audio_list]
+
+
+def normalize(audio, norm="peak"):
+    """SonicSim_audio.py:49-66 (host utility; not on the hot path)."""
+    if norm == "peak":
+        peak = abs(audio).max()
+        return audio / peak if peak != 0 else audio
+    if norm == "rms":
+        a = audio.numpy() if hasattr(audio, "numpy") else np.asarray(audio)
+        rms = np.sqrt(np.mean(np.square(np.trim_zeros(a, trim="b")))) * 100
+        return a / rms if rms != 0 else a
+    raise NotImplementedError
+
+
+def generate_rir_combination(room: str, source_idx_list, receiver_idx_list, receiver_rotation_list,
+                             mic_array_list=None, channel_type: str = "Binaural", channel_order: int = 0, device=None):
+    """SonicSim_audio.py:342-400.  Returns torch.Tensor (S, R, C, L) float32, globally peak-normalised.
+
+    ``channel_order`` defaults to 0 exactly like the reference (:349) -- 'Ambisonics' from SonicSet.py
+    therefore yields ONE channel unless the caller overrides it.  ``device='cuda'`` (extension) keeps the
+    bank in HBM: generation, clip, stack and normalisation then never leave the GPU."""
+    import torch
+
+    src_pairs, rcv_pairs = all_pairs(source_idx_list, receiver_idx_list)
+    _, rot_pairs = all_pairs(source_idx_list, receiver_rotation_list)
+    ir_list = render_rir_parallel([room] * len(src_pairs), src_pairs, rcv_pairs, receiver_rotation_list=rot_pairs,
+                                  mic_array_list=mic_array_list, filename_list=None, channel_type=channel_type,
+                                  channel_order=channel_order, device=device)
+    ir_list = clip_all(ir_list)
+    num_channel = len(ir_list[0])
+    bank = torch.stack(ir_list).reshape(len(source_idx_list), len(receiver_idx_list), num_channel, -1).contiguous()
+    ops.peak_normalize_(bank)                       # ir_output /= ir_output.abs().max()   (:398)
+    return bank
+
+
+# ----------------------------------------------------------------------------- row U
+def k_weighting_coefficients(rate: float) -> np.ndarray:
+    """The two default pyloudnorm K-weighting stages as rows {b0,b1,b2,a0,a1,a2} (un-normalised):
+    high shelf (G=+4 dB, Q=1/sqrt2, fc=1500 Hz) then high pass (Q=0.5, fc=38 Hz)."""
+    rows = []
+    for gain_db, q, fc, kind in ((4.0, 1.0 / math.sqrt(2.0), 1500.0, "shelf"), (0.0, 0.5, 38.0, "hp")):
+        A = 10.0 ** (gain_db / 40.0)
+        w0 = 2.0 * math.pi * (fc / rate)
+        alpha = math.sin(w0) / (2.0 * q)
+        cw = math.cos(w0)
+        if kind == "shelf":
+            sq = 2.0 * math.sqrt(A) * alpha
+            rows.append([A * ((A + 1) + (A - 1) * cw + sq), -2 * A * ((A - 1) + (A + 1) * cw), A * ((A + 1) + (A - 1) * cw - sq),
+                         (A + 1) - (A - 1) * cw + sq, 2 * ((A - 1) - (A + 1) * cw), (A + 1) - (A - 1) * cw - sq])
+        else:
+            rows.append([(1 + cw) / 2, -(1 + cw), (1 + cw) / 2, 1 + alpha, -2 * cw, 1 - alpha])
+    return np.array(rows, dtype=np.float64)
+
+
+def gating_blocks(num_samples: int, rate: float, block_size: float):
+    """Block bounds exactly as pyloudnorm forms them (float64 product truncated by int())."""
+    step = 1.0 - 0.75
+    duration = num_samples / rate
+    count = int(np.round(((duration - block_size) / (block_size * step))) + 1)
+    lo = [int(block_size * (j * step) * rate) for j in np.arange(0, count)]
+    hi = [int(block_size * (j * step + 1) * rate) for j in np.arange(0, count)]
+    return np.array(lo, dtype=np.int64), np.array(hi, dtype=np.int64)
+
+
+def _gated_loudness(z: np.ndarray, weights) -> float:
+    """BS.1770-4 two-stage gating over z[channels, blocks]."""
+    wz = np.asarray(weights, dtype=np.float64)[: z.shape[0], None] * z
+    with np.errstate(divide="ignore", invalid="ignore"):
+        block_l = -0.691 + 10.0 * np.log10(wz.sum(axis=0))
+        keep = block_l >= -70.0
+        if keep.any():
+            rel = -0.691 + 10.0 * np.log10((wz[:, keep].mean(axis=1)).sum()) - 10.0
+        else:
+            rel = np.nan
+        keep = (block_l > rel) & (block_l > -70.0)
+        if keep.any():
+            return float(-0.691 + 10.0 * np.log10((wz[:, keep].mean(axis=1)).sum()))
+        return float("-inf")
+
+
+def integrated_loudness(data, rate: float, block_size: float = 0.4, allow_many_channels: bool = False) -> float:
+    """pyloudnorm ``Meter(rate, block_size=...).integrated_loudness(data)``; data (T,) or (T, C)."""
+    is_t = hasattr(data, "dtype") and str(data.dtype).startswith("torch")
+    if not is_t:
+        data = np.asarray(data)
+        if not np.issubdtype(data.dtype, np.floating):
+            raise ValueError("Data must be floating point.")
+    ndim = data.ndim
+    if ndim > 2:
+        raise ValueError("Audio must be 1D or 2D.")
+    n = data.shape[0]
+    nch = 1 if ndim == 1 else data.shape[1]
+    if nch > 5 and not allow_many_channels:
+        raise ValueError("Audio must have five channels or less.")
+    if n < block_size * rate:
+        raise ValueError("Audio must have length greater than the block size.")
+    lo, hi = gating_blocks(n, rate, block_size)
+    z = ops.kweighted_block_power(data, k_weighting_coefficients(rate), lo, hi, block_size * rate, layout_tc=True)
+    weights = G_WEIGHTS if nch <= 5 else (1.0,) * nch
+    return _gated_loudness(z, weights)
+
+
+def lufs_norm(data, sr, norm=-6, allow_many_channels: bool = False):
+    """SonicSim_audio.py:68-81.  data (T, C) (or (T,)).  Returns (normalised data, gain)."""
+    block_size = 0.4 if len(data) / sr >= 0.4 else len(data) / sr
+    loudness = integrated_loudness(data, sr, block_size, allow_many_channels=allow_many_channels)
+    if math.isinf(loudness):
+        loudness = -40
+        print("loudness is inf")
+    linear = float(np.power(10.0, (norm - loudness) / 20.0))       # pyln.normalize.loudness
+    norm_data, (n, d) = ops.scale(data, linear, want_sums=True)
+    gain = n / d if d else 0.0
+    return norm_data, gain
+
+
+def get_lufs_norm_audio(audio, sr=16000, lufs=-6, allow_many_channels: bool = False):
+    """SonicSim_audio.py:83-86: target drawn from the GLOBAL NumPy RNG, U(lufs-2, lufs+2)."""
+    class_lufs = np.random.uniform(lufs - 2, lufs + 2)
+    return lufs_norm(data=audio, sr=sr, norm=class_lufs, allow_many_channels=allow_many_channels)
+
+
+# ----------------------------------------------------------------------------- row X
+def fft_conv(signal, kernel, is_cpu: bool = False):
+    """SonicSim_audio.py:17-47 / SonicSim_rir.py:62-92: FULL linear convolution, length T+L-1.
+    The reference calls ``irfftn`` without the output length, so its result is wrong whenever T+L-1 is
+    odd; this implementation returns the mathematically intended convolution."""
+    import torch
+
+    sig = signal.reshape(-1)
+    ker = kernel.reshape(-1)
+    total = sig.shape[0] + ker.shape[0] - 1
+    if torch.is_tensor(sig) and sig.is_cuda and not is_cpu:
+        padded = torch.nn.functional.pad(sig.to(torch.float32), (0, ker.shape[0] - 1))
+        return ops.convolve_fixed(padded, ker.reshape(1, -1).to(padded.device))[0][:total]
+    sig_np = np.concatenate([np.asarray(sig.detach().cpu() if torch.is_tensor(sig) else sig, dtype=np.float32),
+                             np.zeros(ker.shape[0] - 1, dtype=np.float32)])
+    ker_np = np.asarray(ker.detach().cpu() if torch.is_tensor(ker) else ker, dtype=np.float32).reshape(1, -1)
+    return torch.from_numpy(ops.convolve_fixed(sig_np, ker_np)[0][:total])

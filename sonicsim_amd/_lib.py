@@ -1,0 +1,95 @@
+"""ctypes binding of libsonicsim_hip.so (include/sonicsim_hip.h).
+
+Importing this module does NOT initialise HIP (``SonicSet.py:154`` uses the 'spawn' start method;
+worker processes re-import modules).  The library itself initialises lazily on the first call.
+There is no CPU fallback: a missing library or a missing GPU raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG, "lib", "libsonicsim_hip.so")
+
+FLAG_DEVICE_PTR = 0x1
+FLAG_PATH_OS = 0x10
+FLAG_PATH_DIRECT = 0x20
+FLAG_LAYOUT_TC = 0x100
+
+SS_EINVAL, SS_EHIP, SS_ENOMEM, SS_ENODEV = -1, -2, -3, -4
+
+c_f32p = ctypes.POINTER(ctypes.c_float)
+c_f64p = ctypes.POINTER(ctypes.c_double)
+c_i64p = ctypes.POINTER(ctypes.c_int64)
+c_i32p = ctypes.POINTER(ctypes.c_int32)
+
+
+class SsRirParams(ctypes.Structure):
+    _fields_ = [("P", ctypes.c_int32), ("C", ctypes.c_int32), ("L", ctypes.c_int32),
+                ("fs", ctypes.c_float), ("rt60", ctypes.c_float), ("tail_gain", ctypes.c_float),
+                ("rho", ctypes.c_float), ("seed", ctypes.c_uint32),
+                ("delay", c_i32p), ("dgain", c_f32p)]
+
+
+_SIGS = {
+    "ss_version": (ctypes.c_int, []),
+    "ss_last_error": (ctypes.c_char_p, []),
+    "ss_init": (ctypes.c_int, [ctypes.c_int]),
+    "ss_shutdown": (ctypes.c_int, []),
+    "ss_convolve_moving_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32,
+                                              ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32,
+                                              ctypes.c_void_p]),
+    "ss_convolve_moving_seg_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32,
+                                                  ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p]),
+    "ss_convolve_fixed_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32,
+                                             ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p]),
+    "ss_rir_bank_synth_f32": (ctypes.c_int, [ctypes.POINTER(SsRirParams), ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p]),
+    "ss_peak_normalize_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, c_f32p, ctypes.c_uint32, ctypes.c_void_p]),
+    "ss_rms_db_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, c_f64p, ctypes.c_uint32, ctypes.c_void_p]),
+    "ss_mix_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, c_f32p,
+                                  ctypes.c_float, ctypes.c_void_p, c_f32p, ctypes.c_uint32, ctypes.c_void_p]),
+    "ss_kweighted_block_power_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, c_f64p, c_i64p, c_i64p,
+                                                    ctypes.c_int32, ctypes.c_double, c_f64p, ctypes.c_uint32, ctypes.c_void_p]),
+    "ss_scale_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_float, c_f64p, ctypes.c_uint32,
+                                    ctypes.c_void_p]),
+    "ss_prof_enable": (ctypes.c_int, [ctypes.c_int]),
+    "ss_prof_read": (ctypes.c_int, [ctypes.c_int, c_i64p, c_f64p]),
+}
+
+EXPORTS = tuple(_SIGS)
+_lib = None
+
+
+def load():
+    """Load the shared library (no HIP call is made).  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `python -m sonicsim_amd.build` "
+            "(the MI355X renderer has no CPU fallback)")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def last_error() -> str:
+    return load().ss_last_error().decode("utf-8", "replace")
+
+
+def check(rc: int):
+    """Map C-ABI return codes to the exception types the reference would raise."""
+    if rc == 0:
+        return
+    msg = last_error()
+    if rc == SS_EINVAL:
+        raise ValueError(msg)
+    if rc == SS_ENOMEM:
+        raise MemoryError(msg)
+    raise RuntimeError(f"libsonicsim_hip error {rc}: {msg}")

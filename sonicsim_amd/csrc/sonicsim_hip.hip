@@ -1,0 +1,971 @@
+// sonicsim_hip.hip -- libsonicsim_hip.so: gfx950 kernels + the C-ABI of include/sonicsim_hip.h.
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC (see sonicsim_amd/build.py).
+// Written for CDNA4 only (wave64, 160 KiB LDS, 256 CUs / 8 XCDs); no CUDA compatibility layer.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/sonicsim_hip.h"
+#include "plan.h"
+#include "tvfir_core.h"
+
+using namespace ss;
+
+// =============================================================================================
+// device side
+// =============================================================================================
+struct DevEnv {
+    c32* smem;
+    __device__ __forceinline__ int tid() const { return threadIdx.x; }
+    __device__ __forceinline__ void barrier() const { __syncthreads(); }
+    __device__ __forceinline__ c32* lds() const { return smem; }
+};
+
+// input spectra: one workgroup per 2B window
+__global__ __launch_bounds__(256, 2) void k_xspec(const float* __restrict__ x, int64_t T, const c32* __restrict__ consts,
+                                                  c32* __restrict__ Xs) {
+    __shared__ __attribute__((aligned(16))) c32 smem[LDS_C32];
+    DevEnv env{smem};
+    xspec_body(env, x, T, consts, Xs, (int)blockIdx.x);
+}
+
+// row-stationary partitioned overlap-save: one workgroup per Task, 2 workgroups resident per CU
+__global__ __launch_bounds__(256, 2) void k_os(RenderParams prm) {
+    __shared__ __attribute__((aligned(16))) c32 smem[LDS_C32];
+    DevEnv env{smem};
+    os_body(env, prm, (int)blockIdx.x);
+}
+
+// direct-form fallback / cross-check
+__global__ __launch_bounds__(256) void k_direct(RenderParams prm) {
+    __shared__ __attribute__((aligned(16))) float smemf[DCHUNK + DTILE + DCHUNK];
+    DevEnv env{reinterpret_cast<c32*>(smemf)};
+    direct_body(env, prm, (int)blockIdx.x);
+}
+
+// per-DTILE min/max of idx (explicit schedule): one workgroup per tile
+__global__ __launch_bounds__(256) void k_idx_minmax(const int64_t* __restrict__ idx, int64_t T, int32_t* __restrict__ bmin,
+                                                    int32_t* __restrict__ bmax) {
+    __shared__ long long smin[4], smax[4];
+    const int64_t t0 = (int64_t)blockIdx.x * DTILE;
+    long long lo = 0x7fffffffffffffffLL, hi = -0x7fffffffffffffffLL - 1;
+    for (int i = threadIdx.x; i < DTILE; i += 256) {
+        const int64_t t = t0 + i;
+        if (t < T) {
+            const long long v = idx[t];
+            lo = v < lo ? v : lo;
+            hi = v > hi ? v : hi;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const long long l2 = __shfl_xor(lo, o), h2 = __shfl_xor(hi, o);
+        lo = l2 < lo ? l2 : lo;
+        hi = h2 > hi ? h2 : hi;
+    }
+    if ((threadIdx.x & 63) == 0) { smin[threadIdx.x >> 6] = lo; smax[threadIdx.x >> 6] = hi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < 4; ++i) { lo = smin[i] < lo ? smin[i] : lo; hi = smax[i] > hi ? smax[i] : hi; }
+        // clamp into int32 so out-of-range values are still detected on the host
+        const long long big = 0x7fffffffLL;
+        bmin[blockIdx.x] = (int32_t)(lo < -big ? -big : (lo > big ? big : lo));
+        bmax[blockIdx.x] = (int32_t)(hi < -big ? -big : (hi > big ? big : hi));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K1: synthetic RIR bank (row R).  Thread per (c,t), sequential AR(1) over positions.
+struct RirDev {
+    int32_t P, C, L;
+    float tail_gain, rho, srho;
+    double inv_tau;   // 6.91 / (rt60 * fs)
+    uint32_t seed;
+    const int32_t* delay;
+    const float* dgain;
+};
+
+__device__ __forceinline__ uint32_t fmix32(uint32_t h) {
+    h ^= h >> 16;
+    h *= 0x85EBCA6Bu;
+    h ^= h >> 13;
+    h *= 0xC2B2AE35u;
+    h ^= h >> 16;
+    return h;
+}
+__device__ __forceinline__ uint32_t hash32(uint32_t seed, uint32_t stream, uint64_t ctr) {
+    const uint32_t k = seed * 0x9E3779B9u + stream;
+    uint32_t h = fmix32((uint32_t)(ctr >> 32) ^ k);
+    return fmix32((uint32_t)ctr ^ h);
+}
+__device__ __forceinline__ float gauss_hash(uint32_t seed, uint64_t ctr) {
+    const float u1 = ((float)(hash32(seed, 1u, ctr) >> 8) + 0.5f) * 5.9604644775390625e-8f;
+    const float u2 = ((float)(hash32(seed, 2u, ctr) >> 8) + 0.5f) * 5.9604644775390625e-8f;
+    return sqrtf(-2.0f * logf(u1)) * cospif(2.0f * u2);
+}
+
+__global__ __launch_bounds__(256) void k_rir_synth(RirDev p, float* __restrict__ bank) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t CL = (int64_t)p.C * p.L;
+    if (i >= CL) return;
+    const int c = (int)(i / p.L);
+    const int t = (int)(i - (int64_t)c * p.L);
+    const float env = (float)exp(-(double)t * p.inv_tau);
+    const float te = p.tail_gain * env;
+    float n = 0.0f;
+    for (int q = 0; q < p.P; ++q) {
+        const uint64_t ctr = ((uint64_t)q * (uint64_t)p.C + (uint64_t)c) * (uint64_t)p.L + (uint64_t)t;
+        const float g = gauss_hash(p.seed, ctr);
+        n = (q == 0) ? g : (p.rho * n + p.srho * g);
+        const int d = p.delay[q * p.C + c];
+        float v = (t > d) ? te * n : 0.0f;
+        if (t == d) v += p.dgain[q * p.C + c];
+        bank[((int64_t)q * p.C + c) * p.L + t] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// reductions / elementwise (rows G, M, U)
+__global__ __launch_bounds__(256) void k_absmax(const float* __restrict__ x, int64_t n, unsigned int* __restrict__ out_bits) {
+    unsigned int m = 0;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        const unsigned int b = __float_as_uint(x[i]) & 0x7fffffffu;
+        m = b > m ? b : m;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned int v = __shfl_xor(m, o);
+        m = v > m ? v : m;
+    }
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(out_bits, m);
+}
+
+__global__ __launch_bounds__(256) void k_divide(float* __restrict__ x, int64_t n, const unsigned int* __restrict__ peak_bits) {
+    const float peak = __uint_as_float(*peak_bits);
+    if (!(peak > 0.0f)) return;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) x[i] = x[i] / peak;   // IEEE division
+}
+
+// deterministic two-stage float64 sums: partial[a][blockIdx.x] then fixed-order final
+template <int KIND>   // 0: sum x^2, 1: sum x
+__global__ __launch_bounds__(256) void k_partial_sum(const float* __restrict__ x, int64_t n, double* __restrict__ partial) {
+    __shared__ double sw[4];
+    const float* xa = x + (int64_t)blockIdx.y * n;
+    double s = 0.0;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        const double v = (double)xa[i];
+        s += KIND == 0 ? v * v : v;
+    }
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = (sw[0] + sw[1]) + (sw[2] + sw[3]);
+}
+__global__ void k_final_sum(const double* __restrict__ partial, int nb, double* __restrict__ out) {
+    if (threadIdx.x == 0) {
+        double s = 0.0;
+        for (int i = 0; i < nb; ++i) s += partial[(int64_t)blockIdx.x * nb + i];
+        out[blockIdx.x] = s;
+    }
+}
+
+__device__ __forceinline__ double rms_db_from_sumsq(double ss_, double n) {
+    const double ms = ss_ / n;
+    return 10.0 * log10(ms > 1e-20 ? ms : 1e-20);
+}
+
+// mix step 2: interferer gains from speaker energies (movingdatamodule.py:106-113)
+__global__ void k_mix_gains1(const double* __restrict__ sumsq, int S, double n, const float* __restrict__ sirs, float* __restrict__ g) {
+    const int i = threadIdx.x;
+    if (i == 0) g[0] = 1.0f;
+    if (i >= 1 && i < S) {
+        const double e0 = rms_db_from_sumsq(sumsq[0], n), ei = rms_db_from_sumsq(sumsq[i], n);
+        double gain = e0 - ei - (double)sirs[i - 1];
+        gain = gain < 40.0 ? gain : 40.0;
+        g[i] = (float)pow(10.0, gain / 20.0);
+    }
+}
+// mix step 3: scale interferers in place, speech sum -> mix, accumulate energies of speech / noise sums
+__global__ __launch_bounds__(256) void k_mix_scale_sum(float* __restrict__ spk, int S, const float* __restrict__ noises, int N,
+                                                       int64_t n, const float* __restrict__ g, float* __restrict__ mix,
+                                                       double* __restrict__ partial /*[2][grid]*/) {
+    __shared__ double sw[2][4];
+    double e_s = 0.0, e_n = 0.0;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        float sp = spk[i];
+        for (int s = 1; s < S; ++s) {
+            const float v = spk[(int64_t)s * n + i] * g[s];
+            spk[(int64_t)s * n + i] = v;
+            sp += v;
+        }
+        float nz = 0.0f;
+        for (int k = 0; k < N; ++k) nz += noises[(int64_t)k * n + i];
+        mix[i] = sp;
+        e_s += (double)sp * (double)sp;
+        e_n += (double)nz * (double)nz;
+    }
+    for (int o = 32; o > 0; o >>= 1) { e_s += __shfl_xor(e_s, o); e_n += __shfl_xor(e_n, o); }
+    if ((threadIdx.x & 63) == 0) { sw[0][threadIdx.x >> 6] = e_s; sw[1][threadIdx.x >> 6] = e_n; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        partial[blockIdx.x] = (sw[0][0] + sw[0][1]) + (sw[0][2] + sw[0][3]);
+        partial[gridDim.x + blockIdx.x] = (sw[1][0] + sw[1][1]) + (sw[1][2] + sw[1][3]);
+    }
+}
+__global__ void k_mix_gains2(const double* __restrict__ sums /*[2]*/, double n, float snr, float* __restrict__ g, int S) {
+    if (threadIdx.x == 0) {
+        double gain = rms_db_from_sumsq(sums[0], n) - rms_db_from_sumsq(sums[1], n) - (double)snr;
+        gain = gain < 40.0 ? gain : 40.0;
+        g[S] = (float)pow(10.0, gain / 20.0);
+    }
+}
+__global__ __launch_bounds__(256) void k_mix_final(const float* __restrict__ noises, int N, int64_t n, const float* __restrict__ g,
+                                                   int S, float* __restrict__ mix) {
+    const float gn = g[S];
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        float nz = 0.0f;
+        for (int k = 0; k < N; ++k) nz += noises[(int64_t)k * n + i];
+        const float scaled = nz * gn;
+        mix[i] = mix[i] + scaled;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_scale(const float* __restrict__ in, float* __restrict__ out, int64_t n, float gain) {
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) out[i] = gain * in[i];
+}
+
+// ---- K-weighting (row U): two cascaded biquads, transposed direct form II (scipy.signal.lfilter),
+// float64 state.  Chunk-parallel: (1) zero-state run per chunk -> end state, (2) sequential state
+// propagation across chunks with the 4x4 chunk transition matrix, (3) re-run from the true state.
+struct KwCoef {
+    double b[2][3], a[2][3];
+    double Mx[16];   // state transition over one full chunk (row-major 4x4)
+};
+constexpr int KW_CHUNK = 1024;
+
+__device__ __forceinline__ double kw_step(const KwCoef& k, double s[4], double xin) {
+    const double y1 = k.b[0][0] * xin + s[0];
+    s[0] = k.b[0][1] * xin - k.a[0][1] * y1 + s[1];
+    s[1] = k.b[0][2] * xin - k.a[0][2] * y1;
+    const double y2 = k.b[1][0] * y1 + s[2];
+    s[2] = k.b[1][1] * y1 - k.a[1][1] * y2 + s[3];
+    s[3] = k.b[1][2] * y1 - k.a[1][2] * y2;
+    return y2;
+}
+
+__global__ __launch_bounds__(64) void k_kw_state(const float* __restrict__ audio, int64_t T, int C, int64_t st, int64_t sc,
+                                                 KwCoef k, int nchunks, double* __restrict__ states /*[C][nchunks][4]*/) {
+    const int id = blockIdx.x * 64 + threadIdx.x;
+    if (id >= C * nchunks) return;
+    const int c = id / nchunks, ch = id - c * nchunks;
+    double s[4] = {0, 0, 0, 0};
+    const int64_t t0 = (int64_t)ch * KW_CHUNK;
+    const int64_t t1 = t0 + KW_CHUNK < T ? t0 + KW_CHUNK : T;
+    for (int64_t t = t0; t < t1; ++t) kw_step(k, s, (double)audio[t * st + c * sc]);
+    double* o = states + ((int64_t)c * nchunks + ch) * 4;
+    o[0] = s[0]; o[1] = s[1]; o[2] = s[2]; o[3] = s[3];
+}
+__global__ void k_kw_scan(KwCoef k, int C, int nchunks, double* __restrict__ states) {
+    const int c = threadIdx.x;
+    if (c >= C) return;
+    double s[4] = {0, 0, 0, 0};
+    for (int ch = 0; ch < nchunks; ++ch) {
+        double* z = states + ((int64_t)c * nchunks + ch) * 4;
+        const double z0 = z[0], z1 = z[1], z2 = z[2], z3 = z[3];
+        z[0] = s[0]; z[1] = s[1]; z[2] = s[2]; z[3] = s[3];     // initial state of this chunk
+        double nx[4];
+        for (int r = 0; r < 4; ++r) nx[r] = k.Mx[r * 4 + 0] * s[0] + k.Mx[r * 4 + 1] * s[1] + k.Mx[r * 4 + 2] * s[2] + k.Mx[r * 4 + 3] * s[3];
+        s[0] = nx[0] + z0; s[1] = nx[1] + z1; s[2] = nx[2] + z2; s[3] = nx[3] + z3;
+    }
+}
+__global__ __launch_bounds__(64) void k_kw_apply(const float* __restrict__ audio, int64_t T, int C, int64_t st, int64_t sc, KwCoef k,
+                                                 int nchunks, const double* __restrict__ states, double* __restrict__ filt /*[C][T]*/) {
+    const int id = blockIdx.x * 64 + threadIdx.x;
+    if (id >= C * nchunks) return;
+    const int c = id / nchunks, ch = id - c * nchunks;
+    const double* z = states + ((int64_t)c * nchunks + ch) * 4;
+    double s[4] = {z[0], z[1], z[2], z[3]};
+    const int64_t t0 = (int64_t)ch * KW_CHUNK;
+    const int64_t t1 = t0 + KW_CHUNK < T ? t0 + KW_CHUNK : T;
+    for (int64_t t = t0; t < t1; ++t) filt[(int64_t)c * T + t] = kw_step(k, s, (double)audio[t * st + c * sc]);
+}
+__global__ __launch_bounds__(256) void k_block_power(const double* __restrict__ filt, int64_t T, const int64_t* __restrict__ lo,
+                                                     const int64_t* __restrict__ hi, int nblocks, double inv_norm,
+                                                     double* __restrict__ z /*[C][nblocks]*/) {
+    __shared__ double sw[4];
+    const int j = blockIdx.x, c = blockIdx.y;
+    int64_t a = lo[j], b = hi[j];
+    a = a < 0 ? 0 : a;
+    b = b > T ? T : b;
+    double s = 0.0;
+    for (int64_t t = a + threadIdx.x; t < b; t += 256) {
+        const double v = filt[(int64_t)c * T + t];
+        s += v * v;
+    }
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) z[(int64_t)c * nblocks + j] = inv_norm * ((sw[0] + sw[1]) + (sw[2] + sw[3]));
+}
+
+// =============================================================================================
+// host side
+// =============================================================================================
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIPCHK(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess) return fail(e_ == hipErrorOutOfMemory ? SS_ENOMEM : SS_EHIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+enum WsSlot { WS_XS, WS_PLAN, WS_BMIN, WS_BMAX, WS_X, WS_BANK, WS_IDX, WS_W, WS_Y, WS_SCR, WS_SCR2, WS_FILT, WS_META, WS_COUNT };
+
+struct Pinned {
+    void* host = nullptr;
+    size_t cap = 0;
+    hipEvent_t ev = nullptr;
+    bool pending = false;
+};
+
+struct EvPair {
+    hipEvent_t a, b;
+    int kind;
+};
+
+struct Ctx {
+    int device = -1;
+    bool inited = false;
+    c32* consts = nullptr;
+    void* ws[WS_COUNT] = {};
+    size_t ws_cap[WS_COUNT] = {};
+    Pinned ring[4];
+    int ring_next = 0;
+    hipStream_t last_stream = nullptr;
+    bool have_last = false;
+    bool prof = false;
+    std::vector<EvPair> evs;
+    // host scratch reused across calls
+    std::vector<int64_t> seg_start;
+    std::vector<int32_t> bmin, bmax;
+    Plan plan;
+};
+
+std::mutex g_mu;
+std::map<int, Ctx*> g_ctx;
+
+int get_ctx(Ctx** out) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return fail(SS_ENODEV, "hipGetDevice failed: %s (no usable GPU; the HIP path has no CPU fallback)", hipGetErrorString(e));
+    auto it = g_ctx.find(dev);
+    Ctx* c;
+    if (it == g_ctx.end()) {
+        c = new Ctx();
+        c->device = dev;
+        g_ctx[dev] = c;
+    } else {
+        c = it->second;
+    }
+    if (!c->inited) {
+        std::vector<c32> tab;
+        build_consts(tab);
+        HIPCHK(hipMalloc((void**)&c->consts, sizeof(c32) * CONST_C32));
+        HIPCHK(hipMemcpy(c->consts, tab.data(), sizeof(c32) * CONST_C32, hipMemcpyHostToDevice));
+        c->inited = true;
+    }
+    *out = c;
+    return SS_OK;
+}
+
+int ws_ensure(Ctx* c, int slot, size_t bytes) {
+    if (bytes == 0) bytes = 16;
+    if (c->ws_cap[slot] >= bytes) return SS_OK;
+    if (c->ws[slot]) HIPCHK(hipFree(c->ws[slot]));   // hipFree synchronises the device
+    c->ws[slot] = nullptr;
+    c->ws_cap[slot] = 0;
+    size_t cap = bytes + bytes / 8;
+    HIPCHK(hipMalloc(&c->ws[slot], cap));
+    c->ws_cap[slot] = cap;
+    return SS_OK;
+}
+
+// stream switch: the workspace is stream-ordered, so serialise against the previous stream
+int stream_enter(Ctx* c, hipStream_t s) {
+    if (c->have_last && c->last_stream != s) HIPCHK(hipStreamSynchronize(c->last_stream));
+    c->last_stream = s;
+    c->have_last = true;
+    return SS_OK;
+}
+
+int pinned_acquire(Ctx* c, size_t bytes, Pinned** out) {
+    Pinned& p = c->ring[c->ring_next];
+    c->ring_next = (c->ring_next + 1) & 3;
+    if (p.pending) {
+        HIPCHK(hipEventSynchronize(p.ev));
+        p.pending = false;
+    }
+    if (!p.ev) HIPCHK(hipEventCreateWithFlags(&p.ev, hipEventDisableTiming));
+    if (p.cap < bytes) {
+        if (p.host) HIPCHK(hipHostFree(p.host));
+        p.host = nullptr;
+        p.cap = 0;
+        HIPCHK(hipHostMalloc(&p.host, bytes + bytes / 4 + 4096, hipHostMallocDefault));
+        p.cap = bytes + bytes / 4 + 4096;
+    }
+    *out = &p;
+    return SS_OK;
+}
+
+struct ProfScope {
+    Ctx* c;
+    hipStream_t s;
+    int kind;
+    bool on;
+    EvPair ev;
+    ProfScope(Ctx* c_, hipStream_t s_, int kind_) : c(c_), s(s_), kind(kind_), on(c_->prof) {
+        if (on) {
+            ev.kind = kind;
+            if (hipEventCreate(&ev.a) != hipSuccess || hipEventCreate(&ev.b) != hipSuccess) { on = false; return; }
+            hipEventRecord(ev.a, s);
+        }
+    }
+    ~ProfScope() {
+        if (on) {
+            hipEventRecord(ev.b, s);
+            c->evs.push_back(ev);
+        }
+    }
+};
+
+inline int grid_for(int64_t n, int cap = 2048) {
+    int64_t g = (n + 255) / 256;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+// ---------------------------------------------------------------------------------------------
+// the render engine shared by rows V / I+V / F
+int render(int mode, const float* x, int64_t T, const float* bank, int32_t P, int32_t C, int32_t L,
+           const int64_t* seg_len_host, const int64_t* idx, const float* w, float* y, uint32_t flags, void* stream_) {
+    if (T < 0 || P < 1 || C < 1 || L < 1) return fail(SS_EINVAL, "bad shape: T=%lld P=%d C=%d L=%d", (long long)T, P, C, L);
+    if (T == 0) return SS_OK;
+    if (!x || !bank || !y) return fail(SS_EINVAL, "NULL data pointer");
+    if (mode != COEF_FIXED && P < 2) return fail(SS_EINVAL, "moving render needs at least 2 positions (P=%d)", P);
+    if (mode == COEF_SEG && !seg_len_host) return fail(SS_EINVAL, "seg_len is NULL");
+    if (mode == COEF_EXPLICIT && (!idx || !w)) return fail(SS_EINVAL, "idx / w is NULL");
+    if (T > (int64_t)2000000000LL * 4) return fail(SS_EINVAL, "T too large");
+    std::lock_guard<std::mutex> lk(g_mu);
+    Ctx* c;
+    int rc = get_ctx(&c);
+    if (rc) return rc;
+    hipStream_t stream = (hipStream_t)stream_;
+    if ((rc = stream_enter(c, stream))) return rc;
+    const bool dev = (flags & SS_FLAG_DEVICE_PTR) != 0;
+
+    // ---- staging for host-pointer mode
+    const float* dx = x;
+    const float* dbank = bank;
+    const int64_t* didx = idx;
+    const float* dw = w;
+    float* dy = y;
+    const size_t bank_bytes = sizeof(float) * (size_t)P * C * L;
+    if (!dev) {
+        if ((rc = ws_ensure(c, WS_X, sizeof(float) * T))) return rc;
+        if ((rc = ws_ensure(c, WS_BANK, bank_bytes))) return rc;
+        if ((rc = ws_ensure(c, WS_Y, sizeof(float) * (size_t)C * T))) return rc;
+        HIPCHK(hipMemcpyAsync(c->ws[WS_X], x, sizeof(float) * T, hipMemcpyHostToDevice, stream));
+        HIPCHK(hipMemcpyAsync(c->ws[WS_BANK], bank, bank_bytes, hipMemcpyHostToDevice, stream));
+        dx = (const float*)c->ws[WS_X];
+        dbank = (const float*)c->ws[WS_BANK];
+        dy = (float*)c->ws[WS_Y];
+        if (mode == COEF_EXPLICIT) {
+            if ((rc = ws_ensure(c, WS_IDX, sizeof(int64_t) * T))) return rc;
+            if ((rc = ws_ensure(c, WS_W, sizeof(float) * T))) return rc;
+            HIPCHK(hipMemcpyAsync(c->ws[WS_IDX], idx, sizeof(int64_t) * T, hipMemcpyHostToDevice, stream));
+            HIPCHK(hipMemcpyAsync(c->ws[WS_W], w, sizeof(float) * T, hipMemcpyHostToDevice, stream));
+            didx = (const int64_t*)c->ws[WS_IDX];
+            dw = (const float*)c->ws[WS_W];
+        }
+    }
+
+    // ---- engine choice
+    bool use_os = L > 128;
+    if (flags & SS_FLAG_PATH_OS) use_os = true;
+    if (flags & SS_FLAG_PATH_DIRECT) use_os = false;
+    const int M = (int)((T + B - 1) / B);
+    const int NPart = (L + B - 1) / B;
+
+    // ---- schedule -> per-tile min/max of idx
+    const int64_t nfine = (T + DTILE - 1) / DTILE;
+    if (mode == COEF_SEG) {
+        c->seg_start.resize(P);
+        int64_t s = 0;
+        for (int k = 0; k < P - 1; ++k) {
+            if (seg_len_host[k] < 0) return fail(SS_EINVAL, "seg_len[%d] = %lld is negative", k, (long long)seg_len_host[k]);
+            c->seg_start[k] = s;
+            s += seg_len_host[k];
+        }
+        c->seg_start[P - 1] = s;
+        if (s != T) return fail(SS_EINVAL, "sum(seg_len) = %lld != T = %lld", (long long)s, (long long)T);
+        seg_minmax(c->seg_start, T, c->bmin, c->bmax);
+    } else if (mode == COEF_EXPLICIT) {
+        if ((rc = ws_ensure(c, WS_BMIN, sizeof(int32_t) * nfine))) return rc;
+        if ((rc = ws_ensure(c, WS_BMAX, sizeof(int32_t) * nfine))) return rc;
+        hipLaunchKernelGGL(k_idx_minmax, dim3((unsigned)nfine), dim3(256), 0, stream, didx, T, (int32_t*)c->ws[WS_BMIN],
+                           (int32_t*)c->ws[WS_BMAX]);
+        HIPCHK(hipGetLastError());
+        c->bmin.resize(nfine);
+        c->bmax.resize(nfine);
+        HIPCHK(hipMemcpyAsync(c->bmin.data(), c->ws[WS_BMIN], sizeof(int32_t) * nfine, hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipMemcpyAsync(c->bmax.data(), c->ws[WS_BMAX], sizeof(int32_t) * nfine, hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        for (int64_t b = 0; b < nfine; ++b)
+            if (c->bmin[b] < 0 || c->bmax[b] > P - 2)
+                return fail(SS_EINVAL, "interp_index out of range [0, %d] near sample %lld (min %d, max %d)", P - 2,
+                            (long long)(b * DTILE), c->bmin[b], c->bmax[b]);
+    }
+    if (mode == COEF_FIXED) build_plan_fixed(T, C, use_os ? B : DTILE, use_os ? JMAX : 1, c->plan);
+    else build_plan(c->bmin, c->bmax, P, C, use_os ? B / DTILE : 1, use_os ? JMAX : 1, c->plan);
+
+    // ---- upload plan blob: [seg_start (P int64)][tasks parity 0][tasks parity 1]
+    const size_t n0 = c->plan.tasks[0].size(), n1 = c->plan.tasks[1].size();
+    const size_t seg_bytes = sizeof(int64_t) * (size_t)P;
+    const size_t blob = seg_bytes + sizeof(Task) * (n0 + n1);
+    Pinned* pin;
+    if ((rc = pinned_acquire(c, blob, &pin))) return rc;
+    if (mode == COEF_SEG) memcpy(pin->host, c->seg_start.data(), seg_bytes); else memset(pin->host, 0, seg_bytes);
+    if (n0) memcpy((char*)pin->host + seg_bytes, c->plan.tasks[0].data(), sizeof(Task) * n0);
+    if (n1) memcpy((char*)pin->host + seg_bytes + sizeof(Task) * n0, c->plan.tasks[1].data(), sizeof(Task) * n1);
+    if ((rc = ws_ensure(c, WS_PLAN, blob))) return rc;
+    HIPCHK(hipMemcpyAsync(c->ws[WS_PLAN], pin->host, blob, hipMemcpyHostToDevice, stream));
+    HIPCHK(hipEventRecord(pin->ev, stream));
+    pin->pending = true;
+
+    RenderParams prm;
+    memset(&prm, 0, sizeof(prm));
+    prm.x = dx; prm.T = T; prm.bank = dbank; prm.P = P; prm.C = C; prm.L = L; prm.NP = NPart;
+    prm.M = M; prm.consts = c->consts; prm.mode = mode;
+    prm.seg_start = (const int64_t*)c->ws[WS_PLAN];
+    prm.idx = didx; prm.w = dw; prm.y = dy;
+
+    if (use_os) {
+        if ((rc = ws_ensure(c, WS_XS, sizeof(c32) * (size_t)M * B))) return rc;
+        prm.Xs = (const c32*)c->ws[WS_XS];
+        {
+            ProfScope ps(c, stream, 1);
+            hipLaunchKernelGGL(k_xspec, dim3(M), dim3(NT), 0, stream, dx, T, (const c32*)c->consts, (c32*)c->ws[WS_XS]);
+        }
+        HIPCHK(hipGetLastError());
+    }
+    const Task* dtasks = (const Task*)((const char*)c->ws[WS_PLAN] + seg_bytes);
+    for (int parity = 0; parity < 2; ++parity) {
+        const size_t nt = parity ? n1 : n0;
+        if (!nt) continue;
+        prm.tasks = dtasks + (parity ? n0 : 0);
+        prm.accumulate = parity;
+        ProfScope ps(c, stream, use_os ? 0 : 2);
+        if (use_os) hipLaunchKernelGGL(k_os, dim3((unsigned)nt), dim3(NT), 0, stream, prm);
+        else hipLaunchKernelGGL(k_direct, dim3((unsigned)nt), dim3(NT), 0, stream, prm);
+    }
+    HIPCHK(hipGetLastError());
+
+    if (!dev) {
+        HIPCHK(hipMemcpyAsync(y, dy, sizeof(float) * (size_t)C * T, hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+    }
+    return SS_OK;
+}
+
+// stage a host array to a workspace slot (or pass a device pointer through)
+int stage_in(Ctx* c, int slot, const void* p, size_t bytes, bool dev, hipStream_t s, const void** out) {
+    if (dev) { *out = p; return SS_OK; }
+    int rc = ws_ensure(c, slot, bytes);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(c->ws[slot], p, bytes, hipMemcpyHostToDevice, s));
+    *out = c->ws[slot];
+    return SS_OK;
+}
+
+}  // namespace
+
+// =============================================================================================
+// C-ABI
+// =============================================================================================
+extern "C" {
+
+int ss_version(void) { return SS_VERSION; }
+const char* ss_last_error(void) { return g_err.c_str(); }
+
+int ss_init(int device) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) return fail(SS_ENODEV, "no HIP device available (%s); the HIP path has no CPU fallback", hipGetErrorString(e));
+    if (device >= 0) {
+        if (device >= n) return fail(SS_EINVAL, "device %d out of range (%d devices)", device, n);
+        HIPCHK(hipSetDevice(device));
+    }
+    Ctx* c;
+    return get_ctx(&c);
+}
+
+int ss_shutdown(void) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (auto& kv : g_ctx) {
+        Ctx* c = kv.second;
+        hipSetDevice(c->device);
+        hipDeviceSynchronize();
+        if (c->consts) hipFree(c->consts);
+        for (int i = 0; i < WS_COUNT; ++i) if (c->ws[i]) hipFree(c->ws[i]);
+        for (auto& p : c->ring) { if (p.host) hipHostFree(p.host); if (p.ev) hipEventDestroy(p.ev); }
+        for (auto& e : c->evs) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
+        delete c;
+    }
+    g_ctx.clear();
+    return SS_OK;
+}
+
+int ss_convolve_moving_f32(const float* x, int64_t T, const float* rirs, int32_t P, int32_t C, int32_t L, const int64_t* idx,
+                           const float* w, float* y, uint32_t flags, void* stream) {
+    return render(COEF_EXPLICIT, x, T, rirs, P, C, L, nullptr, idx, w, y, flags, stream);
+}
+
+int ss_convolve_moving_seg_f32(const float* x, int64_t T, const float* rirs, int32_t P, int32_t C, int32_t L,
+                               const int64_t* seg_len, float* y, uint32_t flags, void* stream) {
+    return render(COEF_SEG, x, T, rirs, P, C, L, seg_len, nullptr, nullptr, y, flags, stream);
+}
+
+int ss_convolve_fixed_f32(const float* x, int64_t T, const float* h, int32_t C, int32_t L, float* y, uint32_t flags,
+                          void* stream) {
+    return render(COEF_FIXED, x, T, h, 1, C, L, nullptr, nullptr, nullptr, y, flags, stream);
+}
+
+int ss_rir_bank_synth_f32(const SsRirParams* p, float* bank, uint32_t flags, void* stream_) {
+    if (!p || !bank || !p->delay || !p->dgain) return fail(SS_EINVAL, "NULL pointer");
+    if (p->P < 1 || p->C < 1 || p->L < 1 || !(p->fs > 0) || !(p->rt60 > 0)) return fail(SS_EINVAL, "bad RIR parameters");
+    if (!(p->rho >= 0.0f && p->rho < 1.0f)) return fail(SS_EINVAL, "rho must be in [0,1)");
+    std::lock_guard<std::mutex> lk(g_mu);
+    Ctx* c;
+    int rc = get_ctx(&c);
+    if (rc) return rc;
+    hipStream_t stream = (hipStream_t)stream_;
+    if ((rc = stream_enter(c, stream))) return rc;
+    const bool dev = (flags & SS_FLAG_DEVICE_PTR) != 0;
+    const size_t pc = (size_t)p->P * p->C;
+    const size_t meta = pc * (sizeof(int32_t) + sizeof(float));
+    Pinned* pin;
+    if ((rc = pinned_acquire(c, meta, &pin))) return rc;
+    memcpy(pin->host, p->delay, pc * sizeof(int32_t));
+    memcpy((char*)pin->host + pc * sizeof(int32_t), p->dgain, pc * sizeof(float));
+    if ((rc = ws_ensure(c, WS_META, meta))) return rc;
+    HIPCHK(hipMemcpyAsync(c->ws[WS_META], pin->host, meta, hipMemcpyHostToDevice, stream));
+    HIPCHK(hipEventRecord(pin->ev, stream));
+    pin->pending = true;
+    const size_t bytes = sizeof(float) * pc * p->L;
+    float* dbank = bank;
+    if (!dev) {
+        if ((rc = ws_ensure(c, WS_BANK, bytes))) return rc;
+        dbank = (float*)c->ws[WS_BANK];
+    }
+    RirDev d;
+    d.P = p->P; d.C = p->C; d.L = p->L;
+    d.tail_gain = p->tail_gain; d.rho = p->rho;
+    d.srho = (float)std::sqrt(1.0 - (double)p->rho * (double)p->rho);
+    d.inv_tau = 6.91 / ((double)p->rt60 * (double)p->fs);
+    d.seed = p->seed;
+    d.delay = (const int32_t*)c->ws[WS_META];
+    d.dgain = (const float*)((const char*)c->ws[WS_META] + pc * sizeof(int32_t));
+    const int64_t CL = (int64_t)p->C * p->L;
+    hipLaunchKernelGGL(k_rir_synth, dim3((unsigned)((CL + 255) / 256)), dim3(256), 0, stream, d, dbank);
+    HIPCHK(hipGetLastError());
+    if (!dev) {
+        HIPCHK(hipMemcpyAsync(bank, dbank, bytes, hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+    }
+    return SS_OK;
+}
+
+int ss_peak_normalize_f32(float* data, int64_t n, float* peak_out, uint32_t flags, void* stream_) {
+    if (n < 0 || (n > 0 && !data)) return fail(SS_EINVAL, "bad argument");
+    if (n == 0) { if (peak_out) *peak_out = 0.0f; return SS_OK; }
+    std::lock_guard<std::mutex> lk(g_mu);
+    Ctx* c;
+    int rc = get_ctx(&c);
+    if (rc) return rc;
+    hipStream_t stream = (hipStream_t)stream_;
+    if ((rc = stream_enter(c, stream))) return rc;
+    const bool dev = (flags & SS_FLAG_DEVICE_PTR) != 0;
+    float* d = data;
+    if (!dev) {
+        if ((rc = ws_ensure(c, WS_BANK, sizeof(float) * n))) return rc;
+        HIPCHK(hipMemcpyAsync(c->ws[WS_BANK], data, sizeof(float) * n, hipMemcpyHostToDevice, stream));
+        d = (float*)c->ws[WS_BANK];
+    }
+    if ((rc = ws_ensure(c, WS_SCR, 64))) return rc;
+    unsigned int* bits = (unsigned int*)c->ws[WS_SCR];
+    HIPCHK(hipMemsetAsync(bits, 0, sizeof(unsigned int), stream));
+    hipLaunchKernelGGL(k_absmax, dim3(grid_for(n)), dim3(256), 0, stream, (const float*)d, n, bits);
+    hipLaunchKernelGGL(k_divide, dim3(grid_for(n)), dim3(256), 0, stream, d, n, (const unsigned int*)bits);
+    HIPCHK(hipGetLastError());
+    if (peak_out) {
+        unsigned int hb = 0;
+        HIPCHK(hipMemcpyAsync(&hb, bits, sizeof(hb), hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        memcpy(peak_out, &hb, sizeof(float));
+    }
+    if (!dev) {
+        HIPCHK(hipMemcpyAsync(data, d, sizeof(float) * n, hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+    }
+    return SS_OK;
+}
+
+int ss_rms_db_f32(const float* x, int64_t n, int32_t count, double* out_db, uint32_t flags, void* stream_) {
+    if (n <= 0 || count <= 0 || !x || !out_db) return fail(SS_EINVAL, "bad argument");
+    std::lock_guard<std::mutex> lk(g_mu);
+    Ctx* c;
+    int rc = get_ctx(&c);
+    if (rc) return rc;
+    hipStream_t stream = (hipStream_t)stream_;
+    if ((rc = stream_enter(c, stream))) return rc;
+    const void* dx;
+    if ((rc = stage_in(c, WS_Y, x, sizeof(float) * (size_t)n * count, (flags & SS_FLAG_DEVICE_PTR) != 0, stream, &dx))) return rc;
+    const int nb = grid_for(n, 512);
+    if ((rc = ws_ensure(c, WS_SCR, sizeof(double) * (size_t)nb * count))) return rc;
+    if ((rc = ws_ensure(c, WS_SCR2, sizeof(double) * count))) return rc;
+    hipLaunchKernelGGL(k_partial_sum<0>, dim3(nb, count), dim3(256), 0, stream, (const float*)dx, n, (double*)c->ws[WS_SCR]);
+    hipLaunchKernelGGL(k_final_sum, dim3(count), dim3(64), 0, stream, (const double*)c->ws[WS_SCR], nb, (double*)c->ws[WS_SCR2]);
+    HIPCHK(hipGetLastError());
+    std::vector<double> ssq(count);
+    HIPCHK(hipMemcpyAsync(ssq.data(), c->ws[WS_SCR2], sizeof(double) * count, hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    for (int i = 0; i < count; ++i) {
+        const double ms = ssq[i] / (double)n;
+        out_db[i] = 10.0 * std::log10(ms > 1e-20 ? ms : 1e-20);
+    }
+    return SS_OK;
+}
+
+int ss_mix_f32(float* speakers, int32_t S, const float* noises, int32_t N, int64_t n, const float* sirs, float snr, float* mix,
+               float* gains_out, uint32_t flags, void* stream_) {
+    if (S < 1 || N < 1 || n <= 0 || !speakers || !noises || !mix || (S > 1 && !sirs)) return fail(SS_EINVAL, "bad argument");
+    if (S > 64) return fail(SS_EINVAL, "too many speakers");
+    std::lock_guard<std::mutex> lk(g_mu);
+    Ctx* c;
+    int rc = get_ctx(&c);
+    if (rc) return rc;
+    hipStream_t stream = (hipStream_t)stream_;
+    if ((rc = stream_enter(c, stream))) return rc;
+    const bool dev = (flags & SS_FLAG_DEVICE_PTR) != 0;
+    float* dspk = speakers;
+    const float* dnoise = noises;
+    float* dmix = mix;
+    if (!dev) {
+        if ((rc = ws_ensure(c, WS_Y, sizeof(float) * (size_t)S * n))) return rc;
+        if ((rc = ws_ensure(c, WS_BANK, sizeof(float) * (size_t)N * n))) return rc;
+        if ((rc = ws_ensure(c, WS_X, sizeof(float) * (size_t)n))) return rc;
+        HIPCHK(hipMemcpyAsync(c->ws[WS_Y], speakers, sizeof(float) * (size_t)S * n, hipMemcpyHostToDevice, stream));
+        HIPCHK(hipMemcpyAsync(c->ws[WS_BANK], noises, sizeof(float) * (size_t)N * n, hipMemcpyHostToDevice, stream));
+        dspk = (float*)c->ws[WS_Y];
+        dnoise = (const float*)c->ws[WS_BANK];
+        dmix = (float*)c->ws[WS_X];
+    }
+    const int nb = grid_for(n, 512);
+    const size_t scr = sizeof(double) * (size_t)nb * (S > 2 ? S : 2);
+    if ((rc = ws_ensure(c, WS_SCR, scr))) return rc;
+    // WS_SCR2: [S doubles sumsq][2 doubles][S+1 floats gains][S floats sirs]
+    const size_t off_s2 = sizeof(double) * S, off_g = off_s2 + sizeof(double) * 2, off_sir = off_g + sizeof(float) * (S + 1);
+    if ((rc = ws_ensure(c, WS_SCR2, off_sir + sizeof(float) * S + 16))) return rc;
+    char* s2 = (char*)c->ws[WS_SCR2];
+    double* d_sumsq = (double*)s2;
+    double* d_s2 = (double*)(s2 + off_s2);
+    float* d_g = (float*)(s2 + off_g);
+    float* d_sir = (float*)(s2 + off_sir);
+    if (S > 1) {
+        Pinned* pin;
+        if ((rc = pinned_acquire(c, sizeof(float) * S, &pin))) return rc;
+        memcpy(pin->host, sirs, sizeof(float) * (S - 1));
+        HIPCHK(hipMemcpyAsync(d_sir, pin->host, sizeof(float) * (S - 1), hipMemcpyHostToDevice, stream));
+        HIPCHK(hipEventRecord(pin->ev, stream));
+        pin->pending = true;
+    }
+    hipLaunchKernelGGL(k_partial_sum<0>, dim3(nb, S), dim3(256), 0, stream, (const float*)dspk, n, (double*)c->ws[WS_SCR]);
+    hipLaunchKernelGGL(k_final_sum, dim3(S), dim3(64), 0, stream, (const double*)c->ws[WS_SCR], nb, d_sumsq);
+    hipLaunchKernelGGL(k_mix_gains1, dim3(1), dim3(64), 0, stream, (const double*)d_sumsq, S, (double)n, (const float*)d_sir, d_g);
+    hipLaunchKernelGGL(k_mix_scale_sum, dim3(nb), dim3(256), 0, stream, dspk, S, dnoise, N, n, (const float*)d_g, dmix,
+                       (double*)c->ws[WS_SCR]);
+    hipLaunchKernelGGL(k_final_sum, dim3(2), dim3(64), 0, stream, (const double*)c->ws[WS_SCR], nb, d_s2);
+    hipLaunchKernelGGL(k_mix_gains2, dim3(1), dim3(64), 0, stream, (const double*)d_s2, (double)n, snr, d_g, S);
+    hipLaunchKernelGGL(k_mix_final, dim3(grid_for(n)), dim3(256), 0, stream, dnoise, N, n, (const float*)d_g, S, dmix);
+    HIPCHK(hipGetLastError());
+    if (gains_out) {
+        std::vector<float> g(S + 1);
+        HIPCHK(hipMemcpyAsync(g.data(), d_g, sizeof(float) * (S + 1), hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        for (int i = 1; i <= S; ++i) gains_out[i - 1] = g[i];
+    }
+    if (!dev) {
+        HIPCHK(hipMemcpyAsync(speakers, dspk, sizeof(float) * (size_t)S * n, hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipMemcpyAsync(mix, dmix, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+    }
+    return SS_OK;
+}
+
+int ss_kweighted_block_power_f32(const float* audio, int64_t T, int32_t C, const double* coef, const int64_t* lo,
+                                 const int64_t* hi, int32_t nblocks, double norm, double* z_out, uint32_t flags, void* stream_) {
+    if (!audio || T <= 0 || C < 1 || C > 64 || !coef || nblocks < 0 || (nblocks && (!lo || !hi)) || !z_out || !(norm > 0))
+        return fail(SS_EINVAL, "bad argument");
+    if (nblocks == 0) return SS_OK;
+    std::lock_guard<std::mutex> lk(g_mu);
+    Ctx* c;
+    int rc = get_ctx(&c);
+    if (rc) return rc;
+    hipStream_t stream = (hipStream_t)stream_;
+    if ((rc = stream_enter(c, stream))) return rc;
+    const void* da;
+    if ((rc = stage_in(c, WS_Y, audio, sizeof(float) * (size_t)C * T, (flags & SS_FLAG_DEVICE_PTR) != 0, stream, &da))) return rc;
+    const bool tc = (flags & SS_FLAG_LAYOUT_TC) != 0;
+    const int64_t st = tc ? C : 1, sc = tc ? 1 : T;
+    KwCoef k;
+    for (int s = 0; s < 2; ++s) {
+        const double a0 = coef[s * 6 + 3];
+        if (a0 == 0.0) return fail(SS_EINVAL, "a0 == 0");
+        for (int i = 0; i < 3; ++i) { k.b[s][i] = coef[s * 6 + i] / a0; k.a[s][i] = coef[s * 6 + 3 + i] / a0; }
+    }
+    // chunk transition matrix: zero-input response of the cascade from the 4 unit states
+    for (int u = 0; u < 4; ++u) {
+        double s[4] = {0, 0, 0, 0};
+        s[u] = 1.0;
+        for (int t = 0; t < KW_CHUNK; ++t) {
+            const double y1 = s[0];
+            s[0] = -k.a[0][1] * y1 + s[1];
+            s[1] = -k.a[0][2] * y1;
+            const double y2 = k.b[1][0] * y1 + s[2];
+            s[2] = k.b[1][1] * y1 - k.a[1][1] * y2 + s[3];
+            s[3] = k.b[1][2] * y1 - k.a[1][2] * y2;
+        }
+        for (int r = 0; r < 4; ++r) k.Mx[r * 4 + u] = s[r];
+    }
+    const int nchunks = (int)((T + KW_CHUNK - 1) / KW_CHUNK);
+    if ((rc = ws_ensure(c, WS_SCR, sizeof(double) * 4 * (size_t)C * nchunks))) return rc;
+    if ((rc = ws_ensure(c, WS_FILT, sizeof(double) * (size_t)C * T))) return rc;
+    const size_t bb = sizeof(int64_t) * (size_t)nblocks;
+    if ((rc = ws_ensure(c, WS_META, 2 * bb))) return rc;
+    if ((rc = ws_ensure(c, WS_SCR2, sizeof(double) * (size_t)C * nblocks))) return rc;
+    Pinned* pin;
+    if ((rc = pinned_acquire(c, 2 * bb, &pin))) return rc;
+    memcpy(pin->host, lo, bb);
+    memcpy((char*)pin->host + bb, hi, bb);
+    HIPCHK(hipMemcpyAsync(c->ws[WS_META], pin->host, 2 * bb, hipMemcpyHostToDevice, stream));
+    HIPCHK(hipEventRecord(pin->ev, stream));
+    pin->pending = true;
+    const int nthreads = C * nchunks;
+    hipLaunchKernelGGL(k_kw_state, dim3((nthreads + 63) / 64), dim3(64), 0, stream, (const float*)da, T, C, st, sc, k, nchunks,
+                       (double*)c->ws[WS_SCR]);
+    hipLaunchKernelGGL(k_kw_scan, dim3(1), dim3(64), 0, stream, k, C, nchunks, (double*)c->ws[WS_SCR]);
+    hipLaunchKernelGGL(k_kw_apply, dim3((nthreads + 63) / 64), dim3(64), 0, stream, (const float*)da, T, C, st, sc, k, nchunks,
+                       (const double*)c->ws[WS_SCR], (double*)c->ws[WS_FILT]);
+    hipLaunchKernelGGL(k_block_power, dim3(nblocks, C), dim3(256), 0, stream, (const double*)c->ws[WS_FILT], T,
+                       (const int64_t*)c->ws[WS_META], (const int64_t*)((const char*)c->ws[WS_META] + bb), nblocks, 1.0 / norm,
+                       (double*)c->ws[WS_SCR2]);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(z_out, c->ws[WS_SCR2], sizeof(double) * (size_t)C * nblocks, hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    return SS_OK;
+}
+
+int ss_scale_f32(const float* in, float* out, int64_t n, float gain, double* sums_out, uint32_t flags, void* stream_) {
+    if (n <= 0 || !in || !out) return fail(SS_EINVAL, "bad argument");
+    std::lock_guard<std::mutex> lk(g_mu);
+    Ctx* c;
+    int rc = get_ctx(&c);
+    if (rc) return rc;
+    hipStream_t stream = (hipStream_t)stream_;
+    if ((rc = stream_enter(c, stream))) return rc;
+    const bool dev = (flags & SS_FLAG_DEVICE_PTR) != 0;
+    const void* din;
+    if ((rc = stage_in(c, WS_Y, in, sizeof(float) * (size_t)n, dev, stream, &din))) return rc;
+    float* dout = out;
+    if (!dev) {
+        if ((rc = ws_ensure(c, WS_X, sizeof(float) * (size_t)n))) return rc;
+        dout = (float*)c->ws[WS_X];
+    }
+    hipLaunchKernelGGL(k_scale, dim3(grid_for(n)), dim3(256), 0, stream, (const float*)din, dout, n, gain);
+    HIPCHK(hipGetLastError());
+    if (sums_out) {
+        const int nb = grid_for(n, 512);
+        if ((rc = ws_ensure(c, WS_SCR, sizeof(double) * (size_t)nb * 2))) return rc;
+        if ((rc = ws_ensure(c, WS_SCR2, sizeof(double) * 2))) return rc;
+        double* part = (double*)c->ws[WS_SCR];
+        hipLaunchKernelGGL(k_partial_sum<1>, dim3(nb, 1), dim3(256), 0, stream, (const float*)dout, n, part);
+        hipLaunchKernelGGL(k_partial_sum<1>, dim3(nb, 1), dim3(256), 0, stream, (const float*)din, n, part + nb);
+        hipLaunchKernelGGL(k_final_sum, dim3(2), dim3(64), 0, stream, (const double*)part, nb, (double*)c->ws[WS_SCR2]);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(sums_out, c->ws[WS_SCR2], sizeof(double) * 2, hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+    }
+    if (!dev) {
+        HIPCHK(hipMemcpyAsync(out, dout, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+    }
+    return SS_OK;
+}
+
+int ss_prof_enable(int on) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    Ctx* c;
+    int rc = get_ctx(&c);
+    if (rc) return rc;
+    HIPCHK(hipDeviceSynchronize());
+    for (auto& e : c->evs) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
+    c->evs.clear();
+    c->prof = on != 0;
+    return SS_OK;
+}
+
+int ss_prof_read(int kind, int64_t* launches, double* total_ms) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    Ctx* c;
+    int rc = get_ctx(&c);
+    if (rc) return rc;
+    HIPCHK(hipDeviceSynchronize());
+    int64_t n = 0;
+    double tot = 0.0;
+    for (auto& e : c->evs) {
+        if (e.kind != kind) continue;
+        float ms = 0.0f;
+        HIPCHK(hipEventElapsedTime(&ms, e.a, e.b));
+        tot += ms;
+        ++n;
+    }
+    if (launches) *launches = n;
+    if (total_ms) *total_ms = tot;
+    return SS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,309 @@
+"""Array-level wrappers over the C-ABI (host NumPy arrays or torch ROCm tensors).
+
+Host inputs (``np.ndarray`` / CPU ``torch.Tensor``) -> host-pointer mode: the library stages H2D/D2H
+and returns NumPy arrays.  ``torch`` tensors on a ROCm device -> device-pointer mode: zero copy, work
+is enqueued on torch's current stream, results are torch tensors on the same device.
+PyTorch is plumbing here (device memory + streams); all arithmetic is in libsonicsim_hip.so.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+
+from . import _lib
+
+PATHS = {None: 0, "auto": 0, "os": _lib.FLAG_PATH_OS, "direct": _lib.FLAG_PATH_DIRECT}
+
+
+def _is_torch(a) -> bool:
+    return type(a).__module__.startswith("torch") and hasattr(a, "data_ptr")
+
+
+def _is_dev(a) -> bool:
+    return _is_torch(a) and a.is_cuda
+
+
+def _np32(a, name):
+    if _is_torch(a):
+        a = a.detach().cpu().numpy()
+    a = np.asarray(a)
+    if a.dtype != np.float32:
+        a = a.astype(np.float32)      # the renderer computes in float32 (like the reference's own data)
+    return np.ascontiguousarray(a)
+
+
+def _dev32(a, name):
+    import torch
+    if a.dtype != torch.float32:
+        a = a.to(torch.float32)
+    return a.contiguous()
+
+
+def _stream_ptr(t):
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _ptr(a):
+    if _is_torch(a):
+        return ctypes.c_void_p(a.data_ptr())
+    return ctypes.c_void_p(a.ctypes.data)
+
+
+def _set_device(t):
+    import torch
+    if torch.cuda.current_device() != t.device.index:
+        torch.cuda.set_device(t.device)
+
+
+def init(device: int = -1):
+    _lib.check(_lib.load().ss_init(int(device)))
+
+
+def convolve_moving(x, rirs, idx, w, path=None):
+    """Row V (SonicSim_moving.py:63-96).  x (T,), rirs (P,C,L), idx (T,) int, w (T,) -> (C,T)."""
+    lib = _lib.load()
+    flags = PATHS[path]
+    if _is_dev(x) or _is_dev(rirs):
+        import torch
+        dev = x.device if _is_dev(x) else rirs.device
+        x = _dev32(torch.as_tensor(x).to(dev), "x")
+        rirs = _dev32(torch.as_tensor(rirs).to(dev), "rirs")
+        idx = torch.as_tensor(idx).to(device=dev, dtype=torch.int64).contiguous()
+        w = _dev32(torch.as_tensor(w).to(dev), "w")
+        _check_moving_shapes(x, rirs, idx, w)
+        P, C, L = rirs.shape
+        T = x.shape[0]
+        _set_device(x)
+        y = torch.empty((C, T), dtype=torch.float32, device=dev)
+        _lib.check(lib.ss_convolve_moving_f32(_ptr(x), T, _ptr(rirs), P, C, L, _ptr(idx), _ptr(w), _ptr(y),
+                                              flags | _lib.FLAG_DEVICE_PTR, _stream_ptr(x)))
+        return y
+    x = _np32(x, "x")
+    rirs = _np32(rirs, "rirs")
+    if _is_torch(idx):
+        idx = idx.detach().cpu().numpy()
+    idx = np.ascontiguousarray(np.asarray(idx).astype(np.int64, copy=False))
+    w = _np32(w, "w")
+    _check_moving_shapes(x, rirs, idx, w)
+    P, C, L = rirs.shape
+    T = x.shape[0]
+    y = np.empty((C, T), dtype=np.float32)
+    _lib.check(lib.ss_convolve_moving_f32(_ptr(x), T, _ptr(rirs), P, C, L, _ptr(idx), _ptr(w), _ptr(y), flags, None))
+    return y
+
+
+def _check_moving_shapes(x, rirs, idx, w):
+    if x.ndim != 1:
+        raise ValueError(f"source_audio must be 1-D (audio_len,), got shape {tuple(x.shape)}")
+    if rirs.ndim != 3:
+        raise ValueError(f"rirs must be (num_positions, num_channels, ir_length), got shape {tuple(rirs.shape)}")
+    if idx.ndim != 1 or w.ndim != 1 or idx.shape[0] != x.shape[0] or w.shape[0] != x.shape[0]:
+        raise ValueError("interp_index / interp_weight must have shape (audio_len,)")
+
+
+def convolve_moving_seg(x, rirs, seg_len, path=None):
+    """Rows I+V fused (SonicSim_moving.py:42-45 + :63-96): seg_len (P-1,) host ints, sum == T."""
+    lib = _lib.load()
+    flags = PATHS[path]
+    seg = np.ascontiguousarray(np.asarray(seg_len).astype(np.int64))
+    if _is_dev(x) or _is_dev(rirs):
+        import torch
+        dev = x.device if _is_dev(x) else rirs.device
+        x = _dev32(torch.as_tensor(x).to(dev), "x")
+        rirs = _dev32(torch.as_tensor(rirs).to(dev), "rirs")
+        if x.ndim != 1 or rirs.ndim != 3 or seg.shape != (rirs.shape[0] - 1,):
+            raise ValueError("shapes: x (T,), rirs (P,C,L), seg_len (P-1,)")
+        P, C, L = rirs.shape
+        T = x.shape[0]
+        _set_device(x)
+        y = torch.empty((C, T), dtype=torch.float32, device=dev)
+        _lib.check(lib.ss_convolve_moving_seg_f32(_ptr(x), T, _ptr(rirs), P, C, L, _ptr(seg), _ptr(y),
+                                                  flags | _lib.FLAG_DEVICE_PTR, _stream_ptr(x)))
+        return y
+    x = _np32(x, "x")
+    rirs = _np32(rirs, "rirs")
+    if x.ndim != 1 or rirs.ndim != 3 or seg.shape != (rirs.shape[0] - 1,):
+        raise ValueError("shapes: x (T,), rirs (P,C,L), seg_len (P-1,)")
+    P, C, L = rirs.shape
+    T = x.shape[0]
+    y = np.empty((C, T), dtype=np.float32)
+    _lib.check(lib.ss_convolve_moving_seg_f32(_ptr(x), T, _ptr(rirs), P, C, L, _ptr(seg), _ptr(y), flags, None))
+    return y
+
+
+def convolve_fixed(x, h, path=None):
+    """Row F (SonicSim_moving.py:47-61).  x (T,) or (1,T); h (C,L) -> (C,T)."""
+    lib = _lib.load()
+    flags = PATHS[path]
+    if _is_dev(x) or _is_dev(h):
+        import torch
+        dev = x.device if _is_dev(x) else h.device
+        x = _dev32(torch.as_tensor(x).to(dev), "x").reshape(-1)
+        h = _dev32(torch.as_tensor(h).to(dev), "h")
+        if h.ndim != 2:
+            raise ValueError("rirs must be (num_channels, ir_length)")
+        C, L = h.shape
+        T = x.shape[0]
+        _set_device(x)
+        y = torch.empty((C, T), dtype=torch.float32, device=dev)
+        _lib.check(lib.ss_convolve_fixed_f32(_ptr(x), T, _ptr(h), C, L, _ptr(y), flags | _lib.FLAG_DEVICE_PTR, _stream_ptr(x)))
+        return y
+    x = _np32(x, "x").reshape(-1)
+    h = _np32(h, "h")
+    if h.ndim != 2:
+        raise ValueError("rirs must be (num_channels, ir_length)")
+    C, L = h.shape
+    T = x.shape[0]
+    y = np.empty((C, T), dtype=np.float32)
+    _lib.check(lib.ss_convolve_fixed_f32(_ptr(x), T, _ptr(h), C, L, _ptr(y), flags, None))
+    return y
+
+
+def rir_bank_synth(delay, dgain, L, fs, rt60, seed, tail_gain=0.05, rho=0.9, device=None):
+    """Row R: synthetic bank (P,C,L) float32.  device=None -> NumPy array; else torch tensor on it."""
+    lib = _lib.load()
+    delay = np.ascontiguousarray(np.asarray(delay, dtype=np.int32))
+    dgain = np.ascontiguousarray(np.asarray(dgain, dtype=np.float32))
+    if delay.ndim != 2 or delay.shape != dgain.shape:
+        raise ValueError("delay / dgain must both be (P, C)")
+    P, C = delay.shape
+    prm = _lib.SsRirParams(P, C, int(L), float(fs), float(rt60), float(tail_gain), float(rho), int(seed) & 0xFFFFFFFF,
+                           delay.ctypes.data_as(_lib.c_i32p), dgain.ctypes.data_as(_lib.c_f32p))
+    if device is None:
+        bank = np.empty((P, C, int(L)), dtype=np.float32)
+        _lib.check(lib.ss_rir_bank_synth_f32(ctypes.byref(prm), _ptr(bank), 0, None))
+        return bank
+    import torch
+    dev = torch.device(device)
+    bank = torch.empty((P, C, int(L)), dtype=torch.float32, device=dev)
+    _set_device(bank)
+    _lib.check(lib.ss_rir_bank_synth_f32(ctypes.byref(prm), _ptr(bank), _lib.FLAG_DEVICE_PTR, _stream_ptr(bank)))
+    return bank
+
+
+def peak_normalize_(a, want_peak=False):
+    """Row G (SonicSim_audio.py:398): in-place a /= abs(a).max().  Returns the peak if asked."""
+    lib = _lib.load()
+    peak = ctypes.c_float(0.0)
+    pp = ctypes.byref(peak) if want_peak else None
+    if _is_dev(a):
+        if not a.is_contiguous() or str(a.dtype) != "torch.float32":
+            raise ValueError("peak_normalize_ needs a contiguous float32 tensor")
+        _set_device(a)
+        _lib.check(lib.ss_peak_normalize_f32(_ptr(a), a.numel(), pp, _lib.FLAG_DEVICE_PTR, _stream_ptr(a)))
+    else:
+        if _is_torch(a):
+            v = a.numpy()
+        else:
+            v = a
+        if v.dtype != np.float32 or not v.flags.c_contiguous:
+            raise ValueError("peak_normalize_ needs a C-contiguous float32 array")
+        _lib.check(lib.ss_peak_normalize_f32(_ptr(v), v.size, pp, 0, None))
+    return float(peak.value) if want_peak else None
+
+
+def rms_db(x):
+    """Row M (movingdatamodule.py:29-32): 10 log10(max(1e-20, mean(x^2))) over all elements."""
+    lib = _lib.load()
+    out = ctypes.c_double(0.0)
+    if _is_dev(x):
+        x = _dev32(x, "x")
+        _set_device(x)
+        _lib.check(lib.ss_rms_db_f32(_ptr(x), x.numel(), 1, ctypes.byref(out), _lib.FLAG_DEVICE_PTR, _stream_ptr(x)))
+    else:
+        x = _np32(x, "x")
+        _lib.check(lib.ss_rms_db_f32(_ptr(x), x.size, 1, ctypes.byref(out), 0, None))
+    return float(out.value)
+
+
+def mix(speaker_wav, noise_wav, sirs, snr):
+    """Row M (movingdatamodule.py:105-124).  speaker_wav (S,...), noise_wav (N,...) same trailing shape.
+    Returns (mix, speaker_wav_scaled, gains).  Device tensors are scaled IN PLACE like the reference."""
+    lib = _lib.load()
+    sirs = np.ascontiguousarray(np.asarray(sirs, dtype=np.float32).reshape(-1))
+    if _is_dev(speaker_wav):
+        import torch
+        spk = _dev32(speaker_wav, "speaker_wav")
+        noi = _dev32(torch.as_tensor(noise_wav).to(spk.device), "noise_wav")
+        S, N = spk.shape[0], noi.shape[0]
+        n = spk[0].numel()
+        if noi[0].numel() != n or sirs.size < S - 1:
+            raise ValueError("shape mismatch between speakers / noises / sirs")
+        out = torch.empty_like(spk[0])
+        gains = np.zeros(S, dtype=np.float32)
+        _set_device(spk)
+        _lib.check(lib.ss_mix_f32(_ptr(spk), S, _ptr(noi), N, n, sirs.ctypes.data_as(_lib.c_f32p), float(snr), _ptr(out),
+                                  gains.ctypes.data_as(_lib.c_f32p), _lib.FLAG_DEVICE_PTR, _stream_ptr(spk)))
+        return out, spk, gains
+    spk = np.array(_np32(speaker_wav, "speaker_wav"), copy=True)
+    noi = _np32(noise_wav, "noise_wav")
+    S, N = spk.shape[0], noi.shape[0]
+    n = spk[0].size
+    if noi[0].size != n or sirs.size < S - 1:
+        raise ValueError("shape mismatch between speakers / noises / sirs")
+    out = np.empty(spk.shape[1:], dtype=np.float32)
+    gains = np.zeros(S, dtype=np.float32)
+    _lib.check(lib.ss_mix_f32(_ptr(spk), S, _ptr(noi), N, n, sirs.ctypes.data_as(_lib.c_f32p), float(snr), _ptr(out),
+                              gains.ctypes.data_as(_lib.c_f32p), 0, None))
+    return out, spk, gains
+
+
+def kweighted_block_power(audio, coef, lo, hi, norm, layout_tc=True):
+    """Row U device part: z[C][nblocks] (float64).  audio (T,C) if layout_tc else (C,T)."""
+    lib = _lib.load()
+    coef = np.ascontiguousarray(np.asarray(coef, dtype=np.float64).reshape(2, 6))
+    lo = np.ascontiguousarray(np.asarray(lo, dtype=np.int64))
+    hi = np.ascontiguousarray(np.asarray(hi, dtype=np.int64))
+    nb = lo.shape[0]
+    flags = _lib.FLAG_LAYOUT_TC if layout_tc else 0
+    if _is_dev(audio):
+        a = _dev32(audio, "audio")
+        if a.ndim == 1:
+            a = a.reshape(-1, 1) if layout_tc else a.reshape(1, -1)
+        T, C = (a.shape[0], a.shape[1]) if layout_tc else (a.shape[1], a.shape[0])
+        z = np.zeros((C, nb), dtype=np.float64)
+        _set_device(a)
+        _lib.check(lib.ss_kweighted_block_power_f32(_ptr(a), T, C, coef.ctypes.data_as(_lib.c_f64p), lo.ctypes.data_as(_lib.c_i64p),
+                                                    hi.ctypes.data_as(_lib.c_i64p), nb, float(norm),
+                                                    z.ctypes.data_as(_lib.c_f64p), flags | _lib.FLAG_DEVICE_PTR, _stream_ptr(a)))
+        return z
+    a = _np32(audio, "audio")
+    if a.ndim == 1:
+        a = a.reshape(-1, 1) if layout_tc else a.reshape(1, -1)
+    T, C = (a.shape[0], a.shape[1]) if layout_tc else (a.shape[1], a.shape[0])
+    z = np.zeros((C, nb), dtype=np.float64)
+    _lib.check(lib.ss_kweighted_block_power_f32(_ptr(a), T, C, coef.ctypes.data_as(_lib.c_f64p), lo.ctypes.data_as(_lib.c_i64p),
+                                                hi.ctypes.data_as(_lib.c_i64p), nb, float(norm), z.ctypes.data_as(_lib.c_f64p),
+                                                flags, None))
+    return z
+
+
+def scale(a, gain, want_sums=False):
+    """out = gain * a (pyloudnorm.normalize.loudness); optional (sum(out), sum(a)) in float64."""
+    lib = _lib.load()
+    sums = (ctypes.c_double * 2)(0.0, 0.0)
+    sp = sums if want_sums else None
+    if _is_dev(a):
+        import torch
+        x = _dev32(a, "a")
+        out = torch.empty_like(x)
+        _set_device(x)
+        _lib.check(lib.ss_scale_f32(_ptr(x), _ptr(out), x.numel(), float(gain), sp, _lib.FLAG_DEVICE_PTR, _stream_ptr(x)))
+    else:
+        x = _np32(a, "a")
+        out = np.empty_like(x)
+        _lib.check(lib.ss_scale_f32(_ptr(x), _ptr(out), x.size, float(gain), sp, 0, None))
+    return (out, (sums[0], sums[1])) if want_sums else out
+
+
+def prof_enable(on=True):
+    _lib.check(_lib.load().ss_prof_enable(1 if on else 0))
+
+
+def prof_read(kind=0):
+    n = ctypes.c_int64(0)
+    ms = ctypes.c_double(0.0)
+    _lib.check(_lib.load().ss_prof_read(int(kind), ctypes.byref(n), ctypes.byref(ms)))
+    return int(n.value), float(ms.value)

@@ -1,0 +1,129 @@
+"""GPU tests for rows R / G / M / U (synthetic bank, peak normalise, mix, loudness)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import loudness as OL
+from oracle import mix as OM
+from oracle import rir_synth as OR
+from util import rel_rms
+
+pytestmark = pytest.mark.gpu
+
+
+def test_rir_bank_synth_matches_numpy_definition(gpu):
+    from sonicsim_amd import ops
+    P, C, L, fs = 7, 3, 5000, 16000
+    rng = np.random.default_rng(3)
+    src = OR.random_walk(P, 33)
+    mics = np.array([5.0, 1.5, 4.0]) + OR.circular_array(C)
+    delay, dgain = OR.delays_and_gains(src, mics, fs)
+    ref = OR.rir_bank_synth(delay, dgain, L, fs, 0.45, 1234)
+    got = ops.rir_bank_synth(delay, dgain, L, fs, 0.45, 1234)
+    assert got.shape == (P, C, L) and got.dtype == np.float32
+    assert np.abs(got - ref).max() < 2e-5 * np.abs(ref).max()
+    assert rel_rms(got, ref) < 1e-5
+    dev = ops.rir_bank_synth(delay, dgain, L, fs, 0.45, 1234, device=gpu)
+    assert np.array_equal(dev.cpu().numpy(), got)                      # deterministic, host == device mode
+    # adjacent positions are correlated (AR(1), rho = 0.9), distant ones are not
+    tail = got[:, 0, 1000:4000]
+    c01 = np.corrcoef(tail[0], tail[1])[0, 1]
+    c06 = np.corrcoef(tail[0], tail[6])[0, 1]
+    assert 0.8 < c01 < 0.97 and abs(c06) < 0.65
+
+
+def test_peak_normalize_bit_exact(gpu):
+    from sonicsim_amd import ops
+    rng = np.random.default_rng(4)
+    a = (rng.standard_normal((5, 2, 3001)) * 3).astype(np.float32)
+    ref = OR.peak_normalise(a)
+    b = a.copy()
+    peak = ops.peak_normalize_(b, want_peak=True)
+    assert peak == np.abs(a).max()
+    assert np.array_equal(b, ref)                                      # IEEE division == NumPy/torch true division
+    t = torch.from_numpy(a).to(gpu)
+    ops.peak_normalize_(t)
+    assert np.array_equal(t.cpu().numpy(), ref)
+    z = np.zeros(10, np.float32)
+    ops.peak_normalize_(z)
+    assert not z.any()
+
+
+def test_generate_rir_combination_contract(gpu):
+    from sonicsim_amd import SonicSim_audio as A, SonicSim_rir as R
+    src = [list(p) for p in OR.random_walk(5, 2)]
+    mic = [5.0, 1.5, 4.0]
+    arr = OR.circular_array(4).tolist()
+    out = A.generate_rir_combination("17DRP5sb8fy", src, [mic], [90], arr, "CustomArrayIR")
+    assert isinstance(out, torch.Tensor) and out.dtype == torch.float32 and out.shape[:3] == (5, 1, 4) and not out.is_cuda
+    assert float(out.abs().max()) == 1.0
+    out2 = A.generate_rir_combination("17DRP5sb8fy", src, [mic], [90], arr, "CustomArrayIR", device="cuda")
+    assert out2.is_cuda and torch.equal(out2.cpu(), out)
+    amb = A.generate_rir_combination("17DRP5sb8fy", src, [mic], [90], None, "Ambisonics")
+    assert amb.shape[2] == 1                                            # channel_order defaults to 0 (SonicSim_audio.py:349)
+    foa = R.render_ir("17DRP5sb8fy", src[0], mic, channel_type="Ambisonics", channel_order=1)
+    assert foa.shape[0] == 4
+    assert R.render_ir("17DRP5sb8fy", src[0], mic, channel_type="Binaural").shape[0] == 2
+    irs = R.render_rir_parallel(["roomA", "roomB", "roomA"], src[:3], [mic] * 3, channel_type="Mono")
+    assert len(irs) == 3 and irs[0].shape[0] == 1 and irs[0].shape == irs[2].shape
+
+
+def test_render_ir_filename_saves_and_returns_none(gpu, tmp_path):
+    from sonicsim_amd import SonicSim_rir as R, wavio
+    p = str(tmp_path / "ir.wav")
+    assert R.render_ir("room", [1, 1.5, 1], [3, 1.5, 2], filename=p, channel_type="Mono") is None
+    w, sr = wavio.load(p)
+    assert sr == 16000 and w.shape[0] == 1 and np.abs(w).max() > 0
+
+
+def test_rms_and_mix(gpu):
+    from sonicsim_amd import mixing, ops
+    rng = np.random.default_rng(9)
+    spk = (rng.standard_normal((3, 2, 40000)) * np.array([0.1, 0.03, 0.3])[:, None, None]).astype(np.float32)
+    noi = (rng.standard_normal((2, 2, 40000)) * 0.05).astype(np.float32)
+    assert abs(ops.rms_db(spk[0]) - OM.compute_mch_rms_dB(spk[0])) < 1e-4
+    assert abs(mixing.compute_mch_rms_dB(np.zeros(100, np.float32)) - (-200.0)) < 1e-9
+    sirs, snr = np.array([2.5, -4.0], np.float32), 12.0
+    ref_mix, ref_spk = OM.mix(spk, noi, sirs, snr)
+    got_mix, got_spk = mixing.mix_sources(spk, noi, sirs, snr)
+    assert rel_rms(got_mix, ref_mix) < 1e-5 and rel_rms(got_spk, ref_spk) < 1e-5
+    assert np.array_equal(got_spk[0], spk[0])
+    td = torch.from_numpy(spk).to(gpu)
+    dmix, dspk = mixing.mix_sources(td, torch.from_numpy(noi).to(gpu), sirs, snr)
+    assert dspk.data_ptr() == td.data_ptr()                             # interferers scaled in place (reference :113)
+    assert np.array_equal(dmix.cpu().numpy(), got_mix)
+    torch.manual_seed(5000)                                             # RNG-drawn SIR/SNR like the reference
+    m1, _ = mixing.mix_sources(spk, noi)
+    torch.manual_seed(5000)
+    s = torch.Tensor(2).uniform_(-6, 6).numpy()
+    n = float(torch.Tensor(1).uniform_(10, 20).numpy()[0])
+    m2, _ = OM.mix(spk, noi, s, n)
+    assert rel_rms(m1, m2) < 1e-5
+
+
+def test_lufs_matches_oracle(gpu):
+    from sonicsim_amd import SonicSim_audio as A
+    rng = np.random.default_rng(10)
+    for fs, T, C in ((16000, 160000, 1), (16000, 100001, 2), (48000, 240000, 4)):
+        env = np.repeat(rng.uniform(0, 1, size=T // 8000 + 1), 8000)[:T]
+        a = (rng.standard_normal((T, C)) * 0.05 * env[:, None]).astype(np.float32)
+        ref = OL.integrated_loudness(a, fs)
+        got = A.integrated_loudness(a, fs)
+        assert abs(got - ref) < 1e-6, (got, ref)
+        np.random.seed(77)
+        rn, rg = OL.get_lufs_norm_audio(a, fs, -17)
+        np.random.seed(77)
+        gn, gg = A.get_lufs_norm_audio(a, fs, -17)
+        assert rel_rms(gn, rn) < 1e-6 and abs(gg - rg) < 1e-5 * abs(rg)
+        assert abs(A.integrated_loudness(gn, fs) - OL.integrated_loudness(rn, fs)) < 1e-5
+    a8 = (rng.standard_normal((32000, 8)) * 0.05).astype(np.float32)
+    with pytest.raises(ValueError, match="five channels"):
+        A.integrated_loudness(a8, 16000)                                 # pyloudnorm rejects > 5 channels
+    got = A.integrated_loudness(a8, 16000, allow_many_channels=True)
+    assert abs(got - OL.integrated_loudness(a8, 16000, allow_many_channels=True)) < 1e-6
+    t = np.arange(48000 * 3) / 48000.0
+    sine = np.sin(2 * np.pi * 997 * t).astype(np.float32)
+    assert abs(A.integrated_loudness(sine, 48000) - (-3.01)) < 0.06       # BS.1770 calibration anchor
+    dev = torch.from_numpy(a8).to(gpu)
+    assert abs(A.integrated_loudness(dev, 16000, allow_many_channels=True) - got) < 1e-9
+    assert A.integrated_loudness(np.zeros((16000, 1), np.float32), 16000) == float("-inf")

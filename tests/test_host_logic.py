@@ -1,0 +1,145 @@
+"""CPU-side tests: host logic of the drop-in modules, C-ABI surface, loud failure without a GPU."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from util import golden
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol(built_lib):
+    hdr = open(os.path.join(ROOT, "include", "sonicsim_hip.h")).read()
+    declared = set(re.findall(r"^\s*(?:int|const char\*)\s+(ss_[a-z0-9_]+)\s*\(", hdr, flags=re.M))
+    assert len(declared) >= 14
+    lib = ctypes.CDLL(built_lib)
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/sonicsim_hip.h but not exported"
+    from sonicsim_amd import _lib
+    assert set(_lib.EXPORTS) == declared
+    assert _lib.load().ss_version() == 100
+
+
+def test_setup_dynamic_interp_matches_reference_golden():
+    from sonicsim_amd import SonicSim_moving as M
+    g = golden("g3_interp.npz")
+    for i in range(int(g["n"])):
+        np.random.seed(int(g[f"seed{i}"]))
+        idx, w = M.setup_dynamic_interp(g[f"pos{i}"], int(g[f"T{i}"]))
+        assert np.array_equal(idx, np.repeat(np.arange(len(g[f"seg_len{i}"])), g[f"seg_len{i}"]))
+        assert w.dtype == np.float32 and np.array_equal(w, g[f"w{i}"])
+        np.random.seed(int(g[f"seed{i}"]))
+        assert np.array_equal(M.segment_lengths(g[f"pos{i}"], int(g[f"T{i}"])), g[f"seg_len{i}"])
+
+
+def test_no_gpu_fails_loudly(built_lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from sonicsim_amd import SonicSim_moving as M
+    with pytest.raises(RuntimeError, match="no CPU fallback|no usable GPU"):
+        M.convolve_fixed_receiver(np.zeros(64, np.float32), np.zeros((1, 8), np.float32))
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "sonicsim_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f"{f} imports the oracle"
+                assert "/root/reference" not in src
+
+
+def test_compat_aliases_resolve():
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); import SonicSim_moving, SonicSim_audio, SonicSim_rir; "
+            "assert SonicSim_moving.interpolate_moving_audio.__module__ == 'sonicsim_amd.SonicSim_moving'; "
+            "assert callable(SonicSim_audio.generate_rir_combination) and callable(SonicSim_rir.render_rir_parallel); "
+            "import torch; assert not torch.cuda.is_initialized()") % os.path.join(ROOT, "sonicsim_amd", "compat")
+    subprocess.run([sys.executable, "-c", code], check=True, cwd="/tmp")
+
+
+def test_signatures_match_reference_contract():
+    """parameter names/defaults the callers in SonicSet.py rely on."""
+    import inspect
+    from sonicsim_amd import SonicSim_audio as A, SonicSim_moving as M, SonicSim_rir as R
+
+    def names(f):
+        return list(inspect.signature(f).parameters)
+
+    assert names(M.interpolate_moving_audio) == ["source1_audio", "ir1_list", "receiver_position"]
+    assert names(M.convolve_moving_receiver) == ["source_audio", "rirs", "interp_index", "interp_weight"]
+    assert names(M.convolve_fixed_receiver) == ["source_audio", "rirs"]
+    assert names(M.setup_dynamic_interp) == ["receiver_position", "total_samples"]
+    assert names(A.generate_rir_combination)[:7] == ["room", "source_idx_list", "receiver_idx_list", "receiver_rotation_list",
+                                                       "mic_array_list", "channel_type", "channel_order"]
+    sig = inspect.signature(A.generate_rir_combination).parameters
+    assert sig["channel_type"].default == "Binaural" and sig["channel_order"].default == 0
+    assert names(R.render_ir)[:9] == ["room", "source_position", "receiver_position", "filename", "receiver_rotation",
+                                       "sample_rate", "use_default_material", "channel_type", "channel_order"]
+    assert names(R.create_custom_arrayir)[:9] == ["room", "source_position", "receiver_position", "mic_array", "filename",
+                                                   "receiver_rotation", "sample_rate", "use_default_material", "channel_order"]
+    assert names(R.render_rir_parallel)[:11] == ["room_list", "source_position_list", "receiver_position_list", "mic_array_list",
+                                                  "filename_list", "receiver_rotation_list", "batch_size", "sample_rate",
+                                                  "use_default_material", "channel_type", "channel_order"]
+    sig = inspect.signature(A.get_lufs_norm_audio).parameters
+    assert sig["sr"].default == 16000 and sig["lufs"].default == -6
+
+
+def test_wav_roundtrip(tmp_path):
+    from sonicsim_amd import wavio
+    a = np.random.default_rng(0).standard_normal((3, 1000)).astype(np.float32)
+    p = str(tmp_path / "a.wav")
+    wavio.save(p, a, 16000)
+    b, sr = wavio.load(p)
+    assert sr == 16000 and np.array_equal(a, b)
+
+
+def test_loudness_host_logic_matches_oracle():
+    """Gating + block bounds + coefficient formulas of the product vs the oracle restatement."""
+    from oracle import loudness as O
+    from sonicsim_amd import SonicSim_audio as A
+    for rate in (16000, 48000, 44100):
+        co = A.k_weighting_coefficients(rate)
+        for s, (b, a) in enumerate(O.k_weighting_coeffs(rate)):
+            np.testing.assert_allclose(co[s, :3] / co[s, 3], b, rtol=1e-14)
+            np.testing.assert_allclose(co[s, 3:] / co[s, 3], a, rtol=1e-14)
+        for n in (int(0.4 * rate), 960000 // 16000 * rate, 123457):
+            lo, hi = A.gating_blocks(n, rate, 0.4)
+            lo2, hi2 = O.block_bounds(n, rate, 0.4)
+            assert np.array_equal(lo, lo2) and np.array_equal(hi, hi2)
+    rng = np.random.default_rng(1)
+    for nch in (1, 2, 5, 8):
+        z = rng.uniform(0, 1e-3, size=(nch, 50)) * (rng.uniform(size=(1, 50)) > 0.3)
+        w = O.G_WEIGHTS if nch <= 5 else [1.0] * nch
+        assert abs(A._gated_loudness(z, w) - O.gate(z, w)) < 1e-9
+    assert A._gated_loudness(np.zeros((2, 10)), O.G_WEIGHTS) == float("-inf")
+
+
+def test_loudness_oracle_calibration():
+    """BS.1770 anchor independent of pyloudnorm: a 0 dBFS 997 Hz sine reads -3.01 LUFS (the RBJ-form
+    K-weighting pyloudnorm evaluates at the actual rate lands within 0.05 dB of it)."""
+    from oracle import loudness as O
+    fs = 48000
+    t = np.arange(fs * 5) / fs
+    x = np.sin(2 * np.pi * 997 * t)
+    l0 = O.integrated_loudness(x, fs)
+    assert abs(l0 - (-3.01)) < 0.06
+    assert abs(O.integrated_loudness(0.1 * x, fs) - (l0 - 20.0)) < 1e-9
+    with pytest.raises(ValueError):
+        O.integrated_loudness(np.zeros((fs, 8)), fs)
+
+
+def test_synth_scene_shapes():
+    from sonicsim_amd import synth
+    sc = synth.make_scene("tiny")
+    assert sc.delay.shape == (sc.P, sc.C) and sc.dgain.dtype == np.float32 and sc.x.shape == (sc.T,)
+    seg = synth.scene_segments(sc)
+    assert seg.sum() == sc.T and seg.shape == (sc.P - 1,)
+    c2 = synth.CONFIGS["cfg2"]
+    assert (c2["T"], c2["P"], c2["C"], c2["L"], c2["fs"]) == (960000, 200, 8, 48000, 16000)
