@@ -70,6 +70,16 @@ def load():
         raise RuntimeError(
             f"{LIB_PATH} is missing: build it with `python -m sonicsim_amd.build` "
             "(the MI355X renderer has no CPU fallback)")
+    # PyTorch-ROCm wheels bundle their own libamdhip64.so.7 / libhsa-runtime64.so.1.  If THIS library were
+    # loaded first it would pull in /opt/rocm's copies and torch would then run against a second HIP/HSA
+    # runtime in the same process ("no ROCm-capable device").  Loading torch first makes the dynamic linker
+    # resolve our NEEDED libamdhip64.so.7 to the already-loaded runtime, so torch tensors, streams and this
+    # library share one runtime.  (Importing torch does not initialise HIP.)  Without torch installed the
+    # system ROCm runtime is used.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in _SIGS.items():
         fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported
