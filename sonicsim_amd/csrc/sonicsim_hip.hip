@@ -5,6 +5,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -29,17 +30,18 @@ struct DevEnv {
 
 // input spectra: one workgroup per 2B window
 __global__ __launch_bounds__(256, 2) void k_xspec(const float* __restrict__ x, int64_t T, const c32* __restrict__ consts,
-                                                  c32* __restrict__ Xs) {
+                                                  c32* __restrict__ Xs, int M) {
     __shared__ __attribute__((aligned(16))) c32 smem[LDS_C32];
     DevEnv env{smem};
-    xspec_body(env, x, T, consts, Xs, (int)blockIdx.x);
+    xspec_body(env, x, T, consts, Xs, (int)blockIdx.x, M);
 }
 
 // row-stationary partitioned overlap-save: one workgroup per Task, 2 workgroups resident per CU
-__global__ __launch_bounds__(256, 2) void k_os(RenderParams prm) {
+// XD = number of input spectra prefetched ahead of the MAC loop (0 = load at use)
+template <int XD, int ABL = 0> __global__ __launch_bounds__(256, 2) void k_os(RenderParams prm) {
     __shared__ __attribute__((aligned(16))) c32 smem[LDS_C32];
     DevEnv env{smem};
-    os_body(env, prm, (int)blockIdx.x);
+    os_body<DevEnv, XD, ABL>(env, prm, (int)blockIdx.x);
 }
 
 // direct-form fallback / cross-check
@@ -367,6 +369,9 @@ struct Ctx {
     bool have_last = false;
     bool prof = false;
     std::vector<EvPair> evs;
+    int os_variant = 3;     // SS_OS_VARIANT: prefetch depth of the render kernel (0, 2, 3) -- tuning knob
+    int os_ablate = 0;      // SS_OS_ABLATE: profiling-only ablation mask (results are WRONG when != 0)
+    bool xcd_order = true;  // SS_XCD_ORDER=0 disables the XCD-aware task order -- tuning knob
     // host scratch reused across calls
     std::vector<int64_t> seg_start;
     std::vector<int32_t> bmin, bmax;
@@ -394,6 +399,9 @@ int get_ctx(Ctx** out) {
         build_consts(tab);
         HIPCHK(hipMalloc((void**)&c->consts, sizeof(c32) * CONST_C32));
         HIPCHK(hipMemcpy(c->consts, tab.data(), sizeof(c32) * CONST_C32, hipMemcpyHostToDevice));
+        if (const char* e = getenv("SS_OS_VARIANT")) c->os_variant = atoi(e);
+        if (const char* e = getenv("SS_OS_ABLATE")) c->os_ablate = atoi(e);
+        if (const char* e = getenv("SS_XCD_ORDER")) c->xcd_order = atoi(e) != 0;
         c->inited = true;
     }
     *out = c;
@@ -550,6 +558,7 @@ int render(int mode, const float* x, int64_t T, const float* bank, int32_t P, in
     }
     if (mode == COEF_FIXED) build_plan_fixed(T, C, use_os ? B : DTILE, use_os ? JMAX : 1, c->plan);
     else build_plan(c->bmin, c->bmax, P, C, use_os ? B / DTILE : 1, use_os ? JMAX : 1, c->plan);
+    if (c->xcd_order) { xcd_interleave(c->plan.tasks[0]); xcd_interleave(c->plan.tasks[1]); }
 
     // ---- upload plan blob: [seg_start (P int64)][tasks parity 0][tasks parity 1]
     const size_t n0 = c->plan.tasks[0].size(), n1 = c->plan.tasks[1].size();
@@ -573,11 +582,11 @@ int render(int mode, const float* x, int64_t T, const float* bank, int32_t P, in
     prm.idx = didx; prm.w = dw; prm.y = dy;
 
     if (use_os) {
-        if ((rc = ws_ensure(c, WS_XS, sizeof(c32) * (size_t)M * B))) return rc;
+        if ((rc = ws_ensure(c, WS_XS, sizeof(c32) * (size_t)(M + 1) * B))) return rc;
         prm.Xs = (const c32*)c->ws[WS_XS];
         {
             ProfScope ps(c, stream, 1);
-            hipLaunchKernelGGL(k_xspec, dim3(M), dim3(NT), 0, stream, dx, T, (const c32*)c->consts, (c32*)c->ws[WS_XS]);
+            hipLaunchKernelGGL(k_xspec, dim3(M + 1), dim3(NT), 0, stream, dx, T, (const c32*)c->consts, (c32*)c->ws[WS_XS], M);
         }
         HIPCHK(hipGetLastError());
     }
@@ -588,8 +597,16 @@ int render(int mode, const float* x, int64_t T, const float* bank, int32_t P, in
         prm.tasks = dtasks + (parity ? n0 : 0);
         prm.accumulate = parity;
         ProfScope ps(c, stream, use_os ? 0 : 2);
-        if (use_os) hipLaunchKernelGGL(k_os, dim3((unsigned)nt), dim3(NT), 0, stream, prm);
-        else hipLaunchKernelGGL(k_direct, dim3((unsigned)nt), dim3(NT), 0, stream, prm);
+        if (!use_os) hipLaunchKernelGGL(k_direct, dim3((unsigned)nt), dim3(NT), 0, stream, prm);
+        else if (c->os_ablate == 1) hipLaunchKernelGGL((k_os<3, 1>), dim3((unsigned)nt), dim3(NT), 0, stream, prm);
+        else if (c->os_ablate == 2) hipLaunchKernelGGL((k_os<3, 2>), dim3((unsigned)nt), dim3(NT), 0, stream, prm);
+        else if (c->os_ablate == 4) hipLaunchKernelGGL((k_os<3, 4>), dim3((unsigned)nt), dim3(NT), 0, stream, prm);
+        else if (c->os_ablate == 3) hipLaunchKernelGGL((k_os<3, 3>), dim3((unsigned)nt), dim3(NT), 0, stream, prm);
+        else if (c->os_ablate == 6) hipLaunchKernelGGL((k_os<3, 6>), dim3((unsigned)nt), dim3(NT), 0, stream, prm);
+        else if (c->os_ablate == 7) hipLaunchKernelGGL((k_os<3, 7>), dim3((unsigned)nt), dim3(NT), 0, stream, prm);
+        else if (c->os_variant == 0) hipLaunchKernelGGL(k_os<0>, dim3((unsigned)nt), dim3(NT), 0, stream, prm);
+        else if (c->os_variant == 2) hipLaunchKernelGGL(k_os<2>, dim3((unsigned)nt), dim3(NT), 0, stream, prm);
+        else hipLaunchKernelGGL(k_os<3>, dim3((unsigned)nt), dim3(NT), 0, stream, prm);
     }
     HIPCHK(hipGetLastError());
 

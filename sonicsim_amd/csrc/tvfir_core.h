@@ -36,6 +36,9 @@ namespace ss {
 struct c32 {
     float x, y;
 };
+struct alignas(16) f4 {
+    float x, y, z, w;
+};
 
 constexpr int B = 2048;   // output block = filter partition = complex FFT length
 constexpr int NT = 256;   // threads per workgroup
@@ -67,7 +70,7 @@ struct RenderParams {
     const float* bank;       // [P][C][L]
     int32_t P, C, L;
     int32_t NP;              // ceil(L / B)
-    const c32* Xs;           // [M][B] input spectra in slot order
+    const c32* Xs;           // [M+1][B] input spectra in slot order; Xs[M] is all zero
     int32_t M;               // ceil(T / B)
     const c32* consts;       // [CONST_C32]
     const Task* tasks;
@@ -298,10 +301,17 @@ SS_HD void emit(const RenderParams& prm, const RowCoef& rc, int chan, int64_t t,
 // Kernel body 1: input spectra.  One workgroup per window m (0 <= m < M):
 //   window m = x[(m-1)B, (m+1)B), zero outside [0,T);  Xs[m][slot] in the layout
 //   c32 index ((r>>1)*256 + tid)*2 + (r&1)  (so the MAC loop reads 16 B per lane, lane-contiguous).
-template <class Env> SS_HD void xspec_body(Env& env, const float* x, int64_t T, const c32* consts, c32* Xs, int m) {
+//   Workgroup m == M writes an all-zero spectrum: out-of-range (block, partition) pairs of the render
+//   kernel read it instead of branching, which keeps the MAC loop free of control flow.
+template <class Env> SS_HD void xspec_body(Env& env, const float* x, int64_t T, const c32* consts, c32* Xs, int m, int M) {
+    const int tid = env.tid();
+    if (m >= M) {   // whole workgroup takes this branch
+        c32* z = Xs + (int64_t)M * B;
+        for (int i = tid; i < B; i += NT) z[i] = mk(0.0f, 0.0f);
+        return;
+    }
     LdsView l; l.base = env.lds();
     load_consts(env, l, consts);
-    const int tid = env.tid();
     c32 v[8];
 #pragma unroll
     for (int n1 = 0; n1 < 8; ++n1) {
@@ -324,11 +334,23 @@ template <class Env> SS_HD void xspec_body(Env& env, const float* x, int64_t T, 
 
 // ---------------------------------------------------------------------------------------------
 // Kernel body 2: row-stationary partitioned overlap-save.  One workgroup per Task.
-template <class Env> SS_HD void os_body(Env& env, const RenderParams& prm, int task_id) {
+//
+// Per partition p:  [issue X loads for the first XD blocks] -> twist -> forward FFT (3 barriers; the X
+// loads and the next partition's taps are in flight underneath) -> 6 block MACs, each consuming a
+// prefetched spectrum and re-issuing the load XD blocks ahead.  (block, partition) pairs that fall
+// before t = 0 or beyond the task's nj blocks read the all-zero spectrum Xs[M]: no control flow in the loop.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define SS_KEEP(x) asm volatile("" ::"v"(x))
+#else
+#define SS_KEEP(x) (void)(x)
+#endif
+// ABL: ablation mask for profiling only (0 in production): 1 = skip forward FFT, 2 = skip MAC, 4 = skip inverse FFT
+template <class Env, int XD, int ABL = 0> SS_HD void os_body(Env& env, const RenderParams& prm, int task_id) {
     LdsView l; l.base = env.lds();
     load_consts(env, l, prm.consts);
     const int tid = env.tid();
     const Task tk = prm.tasks[task_id];
+    if (tk.nj <= 0) return;   // padding task (whole workgroup)
     const float* h = prm.bank + ((int64_t)tk.row * prm.C + tk.chan) * prm.L;
     const int nj = tk.nj, j0 = tk.j0;
 
@@ -342,6 +364,13 @@ template <class Env> SS_HD void os_body(Env& env, const RenderParams& prm, int t
     int np_eff = prm.NP;
     if (np_eff > j0 + nj) np_eff = j0 + nj;
 
+    const f4* Xq = reinterpret_cast<const f4*>(prm.Xs) + tid;     // + m*(B/2) + q*256
+    auto xaddr = [&](int j, int p) -> const f4* {
+        const int m = j0 + j - p;
+        const int me = (j < nj && m >= 0) ? m : prm.M;            // Xs[M] is the zero spectrum
+        return Xq + (int64_t)me * (B / 2);
+    };
+
     float hn[8];
 #pragma unroll
     for (int n1 = 0; n1 < 8; ++n1) {
@@ -349,7 +378,17 @@ template <class Env> SS_HD void os_body(Env& env, const RenderParams& prm, int t
         hn[n1] = (n < prm.L) ? h[n] : 0.0f;
     }
     int par = 0;
+    constexpr int XB = XD > 0 ? XD : 1;
+    f4 xb[XB][4];
     for (int p = 0; p < np_eff; ++p) {
+        if (XD > 0) {
+#pragma unroll
+            for (int j = 0; j < XB; ++j) {
+                const f4* a = xaddr(j, p);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) xb[j][q] = a[q * 256];
+            }
+        }
         c32 v[8];
 #pragma unroll
         for (int n1 = 0; n1 < 8; ++n1) {
@@ -364,19 +403,31 @@ template <class Env> SS_HD void os_body(Env& env, const RenderParams& prm, int t
                 hn[n1] = (n < prm.L) ? h[n] : 0.0f;
             }
         }
-        fft_fwd(env, l, v, par);
+        if (!(ABL & 1)) fft_fwd(env, l, v, par);
+        if (ABL & 2) {
 #pragma unroll
-        for (int j = 0; j < JMAX; ++j) {
-            const int m = j0 + j - p;
-            if (j < nj && m >= 0) {
-                const c32* Xm = prm.Xs + (int64_t)m * B;
+            for (int r = 0; r < 8; ++r) { SS_KEEP(v[r].x); SS_KEEP(v[r].y); }
+        }
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const c32 xa = Xm[(q * 256 + tid) * 2 + 0];
-                    const c32 xb = Xm[(q * 256 + tid) * 2 + 1];
-                    acc[j][2 * q] = cadd(acc[j][2 * q], cmul(xa, v[2 * q]));
-                    acc[j][2 * q + 1] = cadd(acc[j][2 * q + 1], cmul(xb, v[2 * q + 1]));
+        for (int j = 0; j < ((ABL & 2) ? 0 : JMAX); ++j) {
+            f4 xv[4];
+            if (XD > 0) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) xv[q] = xb[j % XB][q];
+                if (j + XB < JMAX) {
+                    const f4* a = xaddr(j + XB, p);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) xb[j % XB][q] = a[q * 256];
                 }
+            } else {
+                const f4* a = xaddr(j, p);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) xv[q] = a[q * 256];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                acc[j][2 * q] = cadd(acc[j][2 * q], cmul(mk(xv[q].x, xv[q].y), v[2 * q]));
+                acc[j][2 * q + 1] = cadd(acc[j][2 * q + 1], cmul(mk(xv[q].z, xv[q].w), v[2 * q + 1]));
             }
         }
     }
@@ -389,7 +440,7 @@ template <class Env> SS_HD void os_body(Env& env, const RenderParams& prm, int t
             c32 v[8];
 #pragma unroll
             for (int r = 0; r < 8; ++r) v[r] = acc[j][r];
-            fft_inv(env, l, v, par);
+            if (!(ABL & 4)) fft_inv(env, l, v, par);
 #pragma unroll
             for (int n1 = 0; n1 < 8; ++n1) {
                 const int n = n1 * 256 + tid;

@@ -62,12 +62,12 @@ int emul_fft_roundtrip(const float* zin /*[2048][2]*/, float* slots /*[2048][2]*
 
 // mode: 0 fixed (P==1), 1 seg (seg_len[P-1]), 2 explicit (idx,w).  path: 0 = overlap-save, 1 = direct
 int emul_render(const float* x, int64_t T, const float* bank, int P, int C, int L, int mode,
-                const int64_t* seg_len, const int64_t* idx, const float* w, float* y, int path, int64_t* ntasks) {
+                const int64_t* seg_len, const int64_t* idx, const float* w, float* y, int path, int64_t* ntasks, int xd) {
     std::vector<c32> consts;
     build_consts(consts);
     const int M = (int)((T + B - 1) / B);
-    std::vector<c32> Xs((size_t)M * B);
-    if (path == 0) launch(M, [&](HostEnv& env, int m) { xspec_body(env, x, T, consts.data(), Xs.data(), m); });
+    std::vector<c32> Xs((size_t)(M + 1) * B);
+    if (path == 0) launch(M + 1, [&](HostEnv& env, int m) { xspec_body(env, x, T, consts.data(), Xs.data(), m, M); });
 
     Plan plan;
     std::vector<int64_t> seg_start;
@@ -105,7 +105,11 @@ int emul_render(const float* x, int64_t T, const float* bank, int P, int C, int 
         prm.tasks = plan.tasks[parity].data();
         prm.accumulate = parity;
         *ntasks += (int64_t)plan.tasks[parity].size();
-        if (path == 0) launch((int)plan.tasks[parity].size(), [&](HostEnv& env, int b) { os_body(env, prm, b); });
+        xcd_interleave(plan.tasks[parity]);
+        prm.tasks = plan.tasks[parity].data();
+        if (path == 0 && xd == 0) launch((int)plan.tasks[parity].size(), [&](HostEnv& env, int b) { os_body<HostEnv, 0>(env, prm, b); });
+        else if (path == 0 && xd == 2) launch((int)plan.tasks[parity].size(), [&](HostEnv& env, int b) { os_body<HostEnv, 2>(env, prm, b); });
+        else if (path == 0) launch((int)plan.tasks[parity].size(), [&](HostEnv& env, int b) { os_body<HostEnv, 3>(env, prm, b); });
         else launch((int)plan.tasks[parity].size(), [&](HostEnv& env, int b) { direct_body(env, prm, b); });
     }
     return 0;

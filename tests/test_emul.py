@@ -29,7 +29,7 @@ def P(a, t=fp):
     return None if a is None else a.ctypes.data_as(t)
 
 
-def render(lib, x, bank, mode, seg=None, idx=None, w=None, path=0):
+def render(lib, x, bank, mode, seg=None, idx=None, w=None, path=0, xd=3):
     x = np.ascontiguousarray(x, np.float32)
     bank = np.ascontiguousarray(bank, np.float32)
     Pn, C, L = bank.shape
@@ -39,7 +39,7 @@ def render(lib, x, bank, mode, seg=None, idx=None, w=None, path=0):
     seg = None if seg is None else np.ascontiguousarray(seg, np.int64)
     idx = None if idx is None else np.ascontiguousarray(idx, np.int64)
     w = None if w is None else np.ascontiguousarray(w, np.float32)
-    rc = lib.emul_render(P(x), ctypes.c_int64(T), P(bank), Pn, C, L, mode, P(seg, ip), P(idx, ip), P(w), P(y), path, ctypes.byref(nt))
+    rc = lib.emul_render(P(x), ctypes.c_int64(T), P(bank), Pn, C, L, mode, P(seg, ip), P(idx, ip), P(w), P(y), path, ctypes.byref(nt), xd)
     assert rc == 0
     return y, nt.value
 
