@@ -134,4 +134,20 @@ inline void build_consts(std::vector<c32>& tab) {
     for (int n = 0; n < 2048; ++n) tab[TWIST_OFF + n] = W((double)n, 8192.0);   // exp(-i pi n / 4096)
 }
 
+inline void build_consts12(std::vector<c32>& tab) {
+    tab.assign(CONST12_C32, c32{0.f, 0.f});
+    const double PI = 3.14159265358979323846264338327950288;
+    auto W = [&](double num, double den) {
+        const double a = -2.0 * PI * num / den;
+        return c32{(float)std::cos(a), (float)std::sin(a)};
+    };
+    for (int k = 1; k < 8; ++k)
+        for (int t = 0; t < 512; ++t) tab[TW1_12 + (k - 1) * 512 + t] = W((double)((t * k) % 4096), 4096.0);
+    for (int k = 1; k < 8; ++k)
+        for (int m = 0; m < 64; ++m) tab[TW2_12 + (k - 1) * 64 + m] = W((double)((m * k) % 512), 512.0);
+    for (int k = 1; k < 8; ++k)
+        for (int n = 0; n < 8; ++n) tab[TW3_12 + (k - 1) * 8 + n] = W((double)((n * k) % 64), 64.0);
+    for (int n = 0; n < 4096; ++n) tab[TWIST_12 + n] = W((double)n, 16384.0);   // exp(-i pi n / 8192)
+}
+
 }  // namespace ss

@@ -44,6 +44,19 @@ template <int XD, int ABL = 0> __global__ __launch_bounds__(256, 2) void k_os(Re
     os_body<DevEnv, XD, ABL>(env, prm, (int)blockIdx.x);
 }
 
+// geometry 12 (B = 4096, 512 threads, sliding spectrum window): one workgroup per CU
+__global__ __launch_bounds__(512, 2) void k_xspec12(const float* __restrict__ x, int64_t T, const c32* __restrict__ consts,
+                                                    c32* __restrict__ Xs, int M) {
+    __shared__ __attribute__((aligned(16))) c32 smem[LDS12_C32];
+    DevEnv env{smem};
+    xspec12_body(env, x, T, consts, Xs, (int)blockIdx.x, M);
+}
+template <int ABL = 0> __global__ __launch_bounds__(512, 2) void k_os12(RenderParams prm) {
+    __shared__ __attribute__((aligned(16))) c32 smem[LDS12_C32];
+    DevEnv env{smem};
+    os12_body<DevEnv, ABL>(env, prm, (int)blockIdx.x);
+}
+
 // direct-form fallback / cross-check
 __global__ __launch_bounds__(256) void k_direct(RenderParams prm) {
     __shared__ __attribute__((aligned(16))) float smemf[DCHUNK + DTILE + DCHUNK];
@@ -361,6 +374,8 @@ struct Ctx {
     int device = -1;
     bool inited = false;
     c32* consts = nullptr;
+    c32* consts12 = nullptr;
+    int os_geom = 0;        // SS_OS_GEOM: 11 (B=2048, 256 thr) / 12 (B=4096, 512 thr, spectrum window); 0 = by filter length
     void* ws[WS_COUNT] = {};
     size_t ws_cap[WS_COUNT] = {};
     Pinned ring[4];
@@ -399,6 +414,10 @@ int get_ctx(Ctx** out) {
         build_consts(tab);
         HIPCHK(hipMalloc((void**)&c->consts, sizeof(c32) * CONST_C32));
         HIPCHK(hipMemcpy(c->consts, tab.data(), sizeof(c32) * CONST_C32, hipMemcpyHostToDevice));
+        build_consts12(tab);
+        HIPCHK(hipMalloc((void**)&c->consts12, sizeof(c32) * CONST12_C32));
+        HIPCHK(hipMemcpy(c->consts12, tab.data(), sizeof(c32) * CONST12_C32, hipMemcpyHostToDevice));
+        if (const char* e = getenv("SS_OS_GEOM")) c->os_geom = atoi(e);
         if (const char* e = getenv("SS_OS_VARIANT")) c->os_variant = atoi(e);
         if (const char* e = getenv("SS_OS_ABLATE")) c->os_ablate = atoi(e);
         if (const char* e = getenv("SS_XCD_ORDER")) c->xcd_order = atoi(e) != 0;
@@ -524,8 +543,11 @@ int render(int mode, const float* x, int64_t T, const float* bank, int32_t P, in
     bool use_os = L > 128;
     if (flags & SS_FLAG_PATH_OS) use_os = true;
     if (flags & SS_FLAG_PATH_DIRECT) use_os = false;
-    const int M = (int)((T + B - 1) / B);
-    const int NPart = (L + B - 1) / B;
+    const bool g12 = use_os && (c->os_geom == 12 || (c->os_geom == 0 && L > 2 * B));
+    const int BB = g12 ? B12 : B;
+    const int JM = g12 ? JMAX12 : JMAX;
+    const int M = (int)((T + BB - 1) / BB);
+    const int NPart = (L + BB - 1) / BB;
 
     // ---- schedule -> per-tile min/max of idx
     const int64_t nfine = (T + DTILE - 1) / DTILE;
@@ -556,8 +578,8 @@ int render(int mode, const float* x, int64_t T, const float* bank, int32_t P, in
                 return fail(SS_EINVAL, "interp_index out of range [0, %d] near sample %lld (min %d, max %d)", P - 2,
                             (long long)(b * DTILE), c->bmin[b], c->bmax[b]);
     }
-    if (mode == COEF_FIXED) build_plan_fixed(T, C, use_os ? B : DTILE, use_os ? JMAX : 1, c->plan);
-    else build_plan(c->bmin, c->bmax, P, C, use_os ? B / DTILE : 1, use_os ? JMAX : 1, c->plan);
+    if (mode == COEF_FIXED) build_plan_fixed(T, C, use_os ? BB : DTILE, use_os ? JM : 1, c->plan);
+    else build_plan(c->bmin, c->bmax, P, C, use_os ? BB / DTILE : 1, use_os ? JM : 1, c->plan);
     if (c->xcd_order) { xcd_interleave(c->plan.tasks[0]); xcd_interleave(c->plan.tasks[1]); }
 
     // ---- upload plan blob: [seg_start (P int64)][tasks parity 0][tasks parity 1]
@@ -577,16 +599,17 @@ int render(int mode, const float* x, int64_t T, const float* bank, int32_t P, in
     RenderParams prm;
     memset(&prm, 0, sizeof(prm));
     prm.x = dx; prm.T = T; prm.bank = dbank; prm.P = P; prm.C = C; prm.L = L; prm.NP = NPart;
-    prm.M = M; prm.consts = c->consts; prm.mode = mode;
+    prm.M = M; prm.consts = g12 ? c->consts12 : c->consts; prm.mode = mode;
     prm.seg_start = (const int64_t*)c->ws[WS_PLAN];
     prm.idx = didx; prm.w = dw; prm.y = dy;
 
     if (use_os) {
-        if ((rc = ws_ensure(c, WS_XS, sizeof(c32) * (size_t)(M + 1) * B))) return rc;
+        if ((rc = ws_ensure(c, WS_XS, sizeof(c32) * (size_t)(M + 1) * BB))) return rc;
         prm.Xs = (const c32*)c->ws[WS_XS];
         {
             ProfScope ps(c, stream, 1);
-            hipLaunchKernelGGL(k_xspec, dim3(M + 1), dim3(NT), 0, stream, dx, T, (const c32*)c->consts, (c32*)c->ws[WS_XS], M);
+            if (g12) hipLaunchKernelGGL(k_xspec12, dim3(M + 1), dim3(NT12), 0, stream, dx, T, (const c32*)c->consts12, (c32*)c->ws[WS_XS], M);
+            else hipLaunchKernelGGL(k_xspec, dim3(M + 1), dim3(NT), 0, stream, dx, T, (const c32*)c->consts, (c32*)c->ws[WS_XS], M);
         }
         HIPCHK(hipGetLastError());
     }
@@ -598,6 +621,11 @@ int render(int mode, const float* x, int64_t T, const float* bank, int32_t P, in
         prm.accumulate = parity;
         ProfScope ps(c, stream, use_os ? 0 : 2);
         if (!use_os) hipLaunchKernelGGL(k_direct, dim3((unsigned)nt), dim3(NT), 0, stream, prm);
+        else if (g12 && c->os_ablate == 1) hipLaunchKernelGGL(k_os12<1>, dim3((unsigned)nt), dim3(NT12), 0, stream, prm);
+        else if (g12 && c->os_ablate == 2) hipLaunchKernelGGL(k_os12<2>, dim3((unsigned)nt), dim3(NT12), 0, stream, prm);
+        else if (g12 && c->os_ablate == 4) hipLaunchKernelGGL(k_os12<4>, dim3((unsigned)nt), dim3(NT12), 0, stream, prm);
+        else if (g12 && c->os_ablate == 7) hipLaunchKernelGGL(k_os12<7>, dim3((unsigned)nt), dim3(NT12), 0, stream, prm);
+        else if (g12) hipLaunchKernelGGL(k_os12<0>, dim3((unsigned)nt), dim3(NT12), 0, stream, prm);
         else if (c->os_ablate == 1) hipLaunchKernelGGL((k_os<3, 1>), dim3((unsigned)nt), dim3(NT), 0, stream, prm);
         else if (c->os_ablate == 2) hipLaunchKernelGGL((k_os<3, 2>), dim3((unsigned)nt), dim3(NT), 0, stream, prm);
         else if (c->os_ablate == 4) hipLaunchKernelGGL((k_os<3, 4>), dim3((unsigned)nt), dim3(NT), 0, stream, prm);
@@ -657,6 +685,7 @@ int ss_shutdown(void) {
         hipSetDevice(c->device);
         hipDeviceSynchronize();
         if (c->consts) hipFree(c->consts);
+        if (c->consts12) hipFree(c->consts12);
         for (int i = 0; i < WS_COUNT; ++i) if (c->ws[i]) hipFree(c->ws[i]);
         for (auto& p : c->ring) { if (p.host) hipHostFree(p.host); if (p.ev) hipEventDestroy(p.ev); }
         for (auto& e : c->evs) { hipEventDestroy(e.a); hipEventDestroy(e.b); }

@@ -33,9 +33,15 @@
 
 namespace ss {
 
+// complex value.  Under hipcc it is a 2-wide float vector so that it lives in an aligned VGPR pair and
+// every complex add/sub/multiply maps onto ONE or TWO packed-f32 instructions (v_pk_add/mul/fma_f32).
+#if defined(__HIPCC__)
+typedef float c32 __attribute__((ext_vector_type(2)));
+#else
 struct c32 {
     float x, y;
 };
+#endif
 struct alignas(16) f4 {
     float x, y, z, w;
 };
@@ -83,45 +89,99 @@ struct RenderParams {
 };
 
 // ---------------------------------------------------------------------------------------------
-// complex helpers
+// complex helpers.  On the device the swizzled forms are written as single packed-f32 instructions with
+// explicit op_sel / neg modifiers: hipcc's SLP vectoriser otherwise spends ~27 % of the issued VALU on
+// v_mov shuffles around packed ops (rocprofv3 / ISA histogram, profiles/r01a).
+//   VOP3P f32 semantics: D.lo = op(S0[op_sel[0]], S1[op_sel[1]]), D.hi = op(S0[op_sel_hi[0]], S1[op_sel_hi[1]]),
+//   neg_lo / neg_hi negate a source for the low / high result.
+#if defined(__HIPCC__)
+SS_HD c32 mk(float x, float y) { c32 r; r.x = x; r.y = y; return r; }
+SS_HD c32 cadd(c32 a, c32 b) { return a + b; }
+SS_HD c32 csub(c32 a, c32 b) { return a - b; }
+SS_HD c32 cscale(c32 a, float s) { return a * s; }
+#else
 SS_HD c32 mk(float x, float y) { c32 r; r.x = x; r.y = y; return r; }
 SS_HD c32 cadd(c32 a, c32 b) { return mk(a.x + b.x, a.y + b.y); }
 SS_HD c32 csub(c32 a, c32 b) { return mk(a.x - b.x, a.y - b.y); }
+SS_HD c32 cscale(c32 a, float s) { return mk(a.x * s, a.y * s); }
+#endif
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define SS_PK2(name, text)                                                        \
+    __device__ __forceinline__ c32 name(c32 a, c32 b) {                            \
+        c32 r;                                                                     \
+        asm("v_pk_add_f32 %0, %1, %2 " text : "=v"(r) : "v"(a), "v"(b));         \
+        return r;                                                                  \
+    }
+SS_PK2(cadd_mi, "op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]")                      // a + (-i) b = (a.x + b.y, a.y - b.x)
+SS_PK2(csub_mi, "op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]")                      // a - (-i) b = (a.x - b.y, a.y + b.x)
+SS_PK2(nadd_mi2, "op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[1,0] neg_hi:[1,1]")        // -a + (-i) b = (-a.x + b.y, -a.y - b.x)
+SS_PK2(nsub_mi2, "op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[1,1] neg_hi:[1,0]")        // -a - (-i) b = (-a.x - b.y, -a.y + b.x)
+#undef SS_PK2
+__device__ __forceinline__ c32 cmul(c32 a, c32 w) {       // a * w
+    c32 t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "v"(w));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "=v"(r) : "v"(a), "v"(w), "v"(t));
+    return r;
+}
+__device__ __forceinline__ c32 cmulc(c32 a, c32 w) {      // a * conj(w)
+    c32 t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1] neg_hi:[0,1]" : "=v"(t) : "v"(a), "v"(w));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(a), "v"(w), "v"(t));
+    return r;
+}
+__device__ __forceinline__ c32 cmac(c32 acc, c32 x, c32 h) {   // acc + x * h
+    c32 t, r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "=v"(t) : "v"(x), "v"(h), "v"(acc));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "=v"(r) : "v"(x), "v"(h), "v"(t));
+    return r;
+}
+#else
+SS_HD c32 cadd_mi(c32 a, c32 b) { return mk(a.x + b.y, a.y - b.x); }
+SS_HD c32 csub_mi(c32 a, c32 b) { return mk(a.x - b.y, a.y + b.x); }
+SS_HD c32 nadd_mi2(c32 a, c32 b) { return mk(-a.x + b.y, -a.y - b.x); }
+SS_HD c32 nsub_mi2(c32 a, c32 b) { return mk(-a.x - b.y, -a.y + b.x); }
 SS_HD c32 cmul(c32 a, c32 b) { return mk(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
-SS_HD c32 cmulc(c32 a, c32 b) { return mk(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }  // a * conj(b)
-template <bool INV> SS_HD c32 ctw(c32 a, c32 w) { return INV ? cmulc(a, w) : cmul(a, w); }
-// multiply by -i (forward) / +i (inverse)
-template <bool INV> SS_HD c32 rot90(c32 a) { return INV ? mk(-a.y, a.x) : mk(a.y, -a.x); }
+SS_HD c32 cmulc(c32 a, c32 b) { return mk(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }   // a * conj(b)
+SS_HD c32 cmac(c32 acc, c32 x, c32 h) { return cadd(acc, cmul(x, h)); }
+#endif
+
+// 8-point DFT, natural in -> natural out (register renaming is free): 28 packed instructions.
+// Forward uses W8 = exp(-i pi/4); INV uses the conjugates.
+template <bool INV> SS_HD void dft8(c32* v) {
+    const float s = 0.70710678118654752440f;
+    const c32 a0 = cadd(v[0], v[4]), a4 = csub(v[0], v[4]);
+    const c32 a1 = cadd(v[1], v[5]), a5 = csub(v[1], v[5]);
+    const c32 a2 = cadd(v[2], v[6]), a6 = csub(v[2], v[6]);
+    const c32 a3 = cadd(v[3], v[7]), a7 = csub(v[3], v[7]);
+    // odd-branch twiddles: b5 = a5 W8^(+-1), b7 = a7 W8^(+-3); the W8^(+-2) = -+i on a6 is folded below
+    const c32 b5 = cscale(INV ? csub_mi(a5, a5) : cadd_mi(a5, a5), s);
+    const c32 b7 = cscale(INV ? nsub_mi2(a7, a7) : nadd_mi2(a7, a7), s);
+    {   // even outputs X0 X2 X4 X6 = DFT4(a0, a1, a2, a3)
+        const c32 c0 = cadd(a0, a2), c1 = csub(a0, a2), c2 = cadd(a1, a3), d = csub(a1, a3);
+        v[0] = cadd(c0, c2);
+        v[4] = csub(c0, c2);
+        v[2] = INV ? csub_mi(c1, d) : cadd_mi(c1, d);
+        v[6] = INV ? cadd_mi(c1, d) : csub_mi(c1, d);
+    }
+    {   // odd outputs X1 X3 X5 X7 = DFT4(a4, b5, -+i a6, b7)
+        const c32 c0 = INV ? csub_mi(a4, a6) : cadd_mi(a4, a6);
+        const c32 c1 = INV ? cadd_mi(a4, a6) : csub_mi(a4, a6);
+        const c32 c2 = cadd(b5, b7), d = csub(b5, b7);
+        v[1] = cadd(c0, c2);
+        v[5] = csub(c0, c2);
+        v[3] = INV ? csub_mi(c1, d) : cadd_mi(c1, d);
+        v[7] = INV ? cadd_mi(c1, d) : csub_mi(c1, d);
+    }
+}
 
 // 4-point DFT (forward: W4 = -i).  in/out natural order.
 template <bool INV> SS_HD void dft4(c32& a0, c32& a1, c32& a2, c32& a3) {
-    c32 c0 = cadd(a0, a2), c1 = csub(a0, a2), c2 = cadd(a1, a3), c3 = rot90<INV>(csub(a1, a3));
+    const c32 c0 = cadd(a0, a2), c1 = csub(a0, a2), c2 = cadd(a1, a3), d = csub(a1, a3);
     a0 = cadd(c0, c2);
     a2 = csub(c0, c2);
-    a1 = cadd(c1, c3);
-    a3 = csub(c1, c3);
-}
-
-// 8-point DFT, natural in -> natural out (register renaming is free).
-template <bool INV> SS_HD void dft8(c32* v) {
-    const float s = 0.70710678118654752440f;
-    c32 a0 = cadd(v[0], v[4]), a4 = csub(v[0], v[4]);
-    c32 a1 = cadd(v[1], v[5]), a5 = csub(v[1], v[5]);
-    c32 a2 = cadd(v[2], v[6]), a6 = csub(v[2], v[6]);
-    c32 a3 = cadd(v[3], v[7]), a7 = csub(v[3], v[7]);
-    // odd branch twiddles W8^1, W8^2, W8^3 (conjugated for the inverse)
-    if (INV) {
-        a5 = mk((a5.x - a5.y) * s, (a5.x + a5.y) * s);     // * (1+i)/sqrt2
-        a7 = mk((-a7.x - a7.y) * s, (a7.x - a7.y) * s);    // * (-1+i)/sqrt2
-    } else {
-        a5 = mk((a5.x + a5.y) * s, (a5.y - a5.x) * s);     // * (1-i)/sqrt2
-        a7 = mk((a7.y - a7.x) * s, (-a7.x - a7.y) * s);    // * (-1-i)/sqrt2
-    }
-    a6 = rot90<INV>(a6);
-    dft4<INV>(a0, a1, a2, a3);   // X0 X2 X4 X6
-    dft4<INV>(a4, a5, a6, a7);   // X1 X3 X5 X7
-    v[0] = a0; v[2] = a1; v[4] = a2; v[6] = a3;
-    v[1] = a4; v[3] = a5; v[5] = a6; v[7] = a7;
+    a1 = INV ? csub_mi(c1, d) : cadd_mi(c1, d);
+    a3 = INV ? cadd_mi(c1, d) : csub_mi(c1, d);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -426,8 +486,8 @@ template <class Env, int XD, int ABL = 0> SS_HD void os_body(Env& env, const Ren
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                acc[j][2 * q] = cadd(acc[j][2 * q], cmul(mk(xv[q].x, xv[q].y), v[2 * q]));
-                acc[j][2 * q + 1] = cadd(acc[j][2 * q + 1], cmul(mk(xv[q].z, xv[q].w), v[2 * q + 1]));
+                acc[j][2 * q] = cmac(acc[j][2 * q], mk(xv[q].x, xv[q].y), v[2 * q]);
+                acc[j][2 * q + 1] = cmac(acc[j][2 * q + 1], mk(xv[q].z, xv[q].w), v[2 * q + 1]);
             }
         }
     }
@@ -447,6 +507,256 @@ template <class Env, int XD, int ABL = 0> SS_HD void os_body(Env& env, const Ren
                 const c32 tw = l.twist()[n];
                 const float val = (v[n1].x * tw.y - v[n1].y * tw.x) * scale;   // -Im(z * conj(tw)) / B
                 emit(prm, rc, tk.chan, (int64_t)(j0 + j) * B + n, val);
+            }
+        }
+    }
+}
+
+// =============================================================================================
+// Geometry 12: B = 4096 = 8^4, 512 threads (8 wave64), JMAX = 4, sliding window of input spectra in VGPRs.
+//
+// Why: with B = 2048 the MAC loop re-reads 6 spectra (96 KB per workgroup) per partition through the
+// 64 B/clk L1 path and is bound there.  With B = 4096 a row touches <= 4 blocks most of the time, the
+// accumulators shrink to 64 VGPRs and the 4 spectra a partition needs are exactly the previous
+// partition's shifted by one block: keep them in registers and load ONE new spectrum per partition
+// (4.4x less L1/L2 traffic, half the barriers per output sample).
+// =============================================================================================
+constexpr int B12 = 4096;
+constexpr int NT12 = 512;
+constexpr int JMAX12 = 4;
+constexpr int TW1_12 = 0;        // [7][512] W_4096^(t*k1)
+constexpr int TW2_12 = 3584;     // [7][64]  W_512^(m2*k2)
+constexpr int TW3_12 = 4032;     // [7][8]   W_64^(n4*k3)
+constexpr int TWIST_12 = 4096;   // [4096]   exp(-i pi n / 8192)
+constexpr int CONST12_C32 = 8192;
+constexpr int EX12_C32 = 5120;   // E1: 4096, E2: 64*72 = 4608, E3: 512*10 = 5120
+constexpr int LDS12_C32 = CONST12_C32 + 2 * EX12_C32;   // 18432 c32 = 147456 bytes
+
+struct Lds12 {
+    c32* base;
+    SS_HD const c32* tw1() const { return base + TW1_12; }
+    SS_HD const c32* tw2() const { return base + TW2_12; }
+    SS_HD const c32* tw3() const { return base + TW3_12; }
+    SS_HD const c32* twist() const { return base + TWIST_12; }
+    SS_HD c32* exA(int par) const { return base + CONST12_C32 + (par ? EX12_C32 : 0); }
+    SS_HD c32* exB(int par) const { return base + CONST12_C32 + (par ? 0 : EX12_C32); }
+};
+
+// Forward 4096-point FFT.  In: v[n1] = z[n1*512 + tid].  Out: slot (tid, r): tid = k1*64 + k2*8 + k3, r = k4,
+// bin = k1 + 8*k2 + 64*k3 + 512*k4.
+template <class Env> SS_HD void fft12_fwd(Env& env, const Lds12& l, c32* v, int& par) {
+    const int tid = env.tid();
+    c32* A = l.exA(par);
+    c32* Bf = l.exB(par);
+    par ^= 1;
+    dft8<false>(v);
+    A[tid] = v[0];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) A[k * 512 + tid] = cmul(v[k], l.tw1()[(k - 1) * 512 + tid]);
+    env.barrier();
+    {
+        const int k1 = tid >> 6, m2 = tid & 63;
+#pragma unroll
+        for (int n = 0; n < 8; ++n) v[n] = A[k1 * 512 + n * 64 + m2];
+        dft8<false>(v);
+        Bf[(k1 * 8) * 72 + m2] = v[0];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) Bf[(k1 * 8 + k) * 72 + m2] = cmul(v[k], l.tw2()[(k - 1) * 64 + m2]);
+    }
+    env.barrier();
+    {
+        const int g = tid >> 3, n4 = tid & 7;
+#pragma unroll
+        for (int n = 0; n < 8; ++n) v[n] = Bf[g * 72 + n * 8 + n4];
+        dft8<false>(v);
+        A[(g * 8) * 10 + n4] = v[0];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) A[(g * 8 + k) * 10 + n4] = cmul(v[k], l.tw3()[(k - 1) * 8 + n4]);
+    }
+    env.barrier();
+    {
+        const c32* p0 = A + tid * 10;
+#pragma unroll
+        for (int n = 0; n < 8; ++n) v[n] = p0[n];
+        dft8<false>(v);
+    }
+}
+
+template <class Env> SS_HD void fft12_inv(Env& env, const Lds12& l, c32* v, int& par) {
+    const int tid = env.tid();
+    c32* A = l.exA(par);
+    c32* Bf = l.exB(par);
+    par ^= 1;
+    {
+        dft8<true>(v);
+        c32* p0 = A + tid * 10;
+#pragma unroll
+        for (int n = 0; n < 8; ++n) p0[n] = v[n];
+    }
+    env.barrier();
+    {
+        const int g = tid >> 3, n4 = tid & 7;
+        v[0] = A[(g * 8) * 10 + n4];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) v[k] = cmulc(A[(g * 8 + k) * 10 + n4], l.tw3()[(k - 1) * 8 + n4]);
+        dft8<true>(v);
+#pragma unroll
+        for (int n = 0; n < 8; ++n) Bf[g * 72 + n * 8 + n4] = v[n];
+    }
+    env.barrier();
+    {
+        const int k1 = tid >> 6, m2 = tid & 63;
+        v[0] = Bf[(k1 * 8) * 72 + m2];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) v[k] = cmulc(Bf[(k1 * 8 + k) * 72 + m2], l.tw2()[(k - 1) * 64 + m2]);
+        dft8<true>(v);
+#pragma unroll
+        for (int n = 0; n < 8; ++n) A[k1 * 512 + n * 64 + m2] = v[n];
+    }
+    env.barrier();
+    {
+        v[0] = A[tid];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) v[k] = cmulc(A[k * 512 + tid], l.tw1()[(k - 1) * 512 + tid]);
+        dft8<true>(v);
+    }
+}
+
+template <class Env> SS_HD void load_consts12(Env& env, const Lds12& l, const c32* consts) {
+    const int tid = env.tid();
+    for (int i = tid; i < CONST12_C32; i += NT12) l.base[i] = consts[i];
+    env.barrier();
+}
+
+// input spectra, B = 4096: slot layout c32 index ((r>>1)*512 + tid)*2 + (r&1); Xs[M] = 0
+template <class Env> SS_HD void xspec12_body(Env& env, const float* x, int64_t T, const c32* consts, c32* Xs, int m, int M) {
+    const int tid = env.tid();
+    if (m >= M) {
+        c32* z = Xs + (int64_t)M * B12;
+        for (int i = tid; i < B12; i += NT12) z[i] = mk(0.0f, 0.0f);
+        return;
+    }
+    Lds12 l; l.base = env.lds();
+    load_consts12(env, l, consts);
+    c32 v[8];
+#pragma unroll
+    for (int n1 = 0; n1 < 8; ++n1) {
+        const int n = n1 * 512 + tid;
+        const int64_t tlo = (int64_t)(m - 1) * B12 + n, thi = (int64_t)m * B12 + n;
+        const float lo = (tlo >= 0 && tlo < T) ? x[tlo] : 0.0f;
+        const float hi = (thi < T) ? x[thi] : 0.0f;
+        const c32 tw = l.twist()[n];
+        v[n1] = mk(lo * tw.x + hi * tw.y, lo * tw.y - hi * tw.x);
+    }
+    int par = 0;
+    fft12_fwd(env, l, v, par);
+    c32* out = Xs + (int64_t)m * B12;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        out[(q * 512 + tid) * 2 + 0] = v[2 * q];
+        out[(q * 512 + tid) * 2 + 1] = v[2 * q + 1];
+    }
+}
+
+// render body, B = 4096, sliding spectrum window in registers
+template <class Env, int ABL = 0> SS_HD void os12_body(Env& env, const RenderParams& prm, int task_id) {
+    Lds12 l; l.base = env.lds();
+    load_consts12(env, l, prm.consts);
+    const int tid = env.tid();
+    const Task tk = prm.tasks[task_id];
+    if (tk.nj <= 0) return;
+    const float* h = prm.bank + ((int64_t)tk.row * prm.C + tk.chan) * prm.L;
+    const int nj = tk.nj, j0 = tk.j0;
+
+    c32 acc[JMAX12][8];
+#pragma unroll
+    for (int j = 0; j < JMAX12; ++j)
+#pragma unroll
+        for (int r = 0; r < 8; ++r) acc[j][r] = mk(0.0f, 0.0f);
+
+    int np_eff = prm.NP;
+    if (np_eff > j0 + nj) np_eff = j0 + nj;
+
+    const f4* Xq = reinterpret_cast<const f4*>(prm.Xs) + tid;     // + m*(B12/2) + q*512
+    auto xaddr = [&](int m) -> const f4* {
+        const int me = (m >= 0 && m < prm.M) ? m : prm.M;         // Xs[M] is the zero spectrum
+        return Xq + (int64_t)me * (B12 / 2);
+    };
+    // window: win[j] = X_{j0 + j - p} for the current partition p
+    f4 win[JMAX12][4];
+#pragma unroll
+    for (int j = 0; j < JMAX12; ++j) {
+        const f4* a = xaddr(j < nj ? j0 + j : -1);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) win[j][q] = a[q * 512];
+    }
+    float hn[8];
+#pragma unroll
+    for (int n1 = 0; n1 < 8; ++n1) {
+        const int n = n1 * 512 + tid;
+        hn[n1] = (n < prm.L) ? h[n] : 0.0f;
+    }
+    int par = 0;
+    for (int p = 0; p < np_eff; ++p) {
+        // the one new spectrum the NEXT partition needs (block 0 at step p+1): in flight under this FFT + MAC
+        f4 nx[4];
+        {
+            const f4* a = xaddr(j0 - (p + 1));
+#pragma unroll
+            for (int q = 0; q < 4; ++q) nx[q] = a[q * 512];
+        }
+        c32 v[8];
+#pragma unroll
+        for (int n1 = 0; n1 < 8; ++n1) {
+            const c32 tw = l.twist()[n1 * 512 + tid];
+            v[n1] = mk(hn[n1] * tw.x, hn[n1] * tw.y);
+        }
+        if (p + 1 < np_eff) {
+#pragma unroll
+            for (int n1 = 0; n1 < 8; ++n1) {
+                const int n = (p + 1) * B12 + n1 * 512 + tid;
+                hn[n1] = (n < prm.L) ? h[n] : 0.0f;
+            }
+        }
+        if (!(ABL & 1)) fft12_fwd(env, l, v, par);
+        if (ABL & 2) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) { SS_KEEP(v[r].x); SS_KEEP(v[r].y); }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { SS_KEEP(nx[q].x); SS_KEEP(nx[q].w); }
+        }
+#pragma unroll
+        for (int j = 0; j < ((ABL & 2) ? 0 : JMAX12); ++j) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                acc[j][2 * q] = cmac(acc[j][2 * q], mk(win[j][q].x, win[j][q].y), v[2 * q]);
+                acc[j][2 * q + 1] = cmac(acc[j][2 * q + 1], mk(win[j][q].z, win[j][q].w), v[2 * q + 1]);
+            }
+        }
+        // slide: block j of the next partition needs what block j-1 used now
+#pragma unroll
+        for (int j = JMAX12 - 1; j > 0; --j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) win[j][q] = win[j - 1][q];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) win[0][q] = nx[q];
+    }
+
+    const RowCoef rc = make_rowcoef(prm, tk.row);
+    const float scale = 1.0f / (float)B12;
+#pragma unroll
+    for (int j = 0; j < JMAX12; ++j) {
+        if (j < nj) {
+            c32 v[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) v[r] = acc[j][r];
+            if (!(ABL & 4)) fft12_inv(env, l, v, par);
+#pragma unroll
+            for (int n1 = 0; n1 < 8; ++n1) {
+                const int n = n1 * 512 + tid;
+                const c32 tw = l.twist()[n];
+                const float val = (v[n1].x * tw.y - v[n1].y * tw.x) * scale;
+                emit(prm, rc, tk.chan, (int64_t)(j0 + j) * B12 + n, val);
             }
         }
     }

@@ -22,12 +22,12 @@ struct HostEnv {
     c32* lds() const { return lds_; }
 };
 
-template <class F> static void launch(int grid, F&& body) {
-    std::vector<c32> lds(LDS_C32);
-    std::barrier<> bar(NT);
+template <class F> static void launch(int grid, F&& body, int nthreads = NT) {
+    std::vector<c32> lds(LDS12_C32);
+    std::barrier<> bar(nthreads);
     std::vector<std::thread> th;
-    th.reserve(NT);
-    for (int t = 0; t < NT; ++t) {
+    th.reserve(nthreads);
+    for (int t = 0; t < nthreads; ++t) {
         th.emplace_back([&, t]() {
             HostEnv env{t, &bar, lds.data()};
             for (int b = 0; b < grid; ++b) {
@@ -60,22 +60,43 @@ int emul_fft_roundtrip(const float* zin /*[2048][2]*/, float* slots /*[2048][2]*
     return 0;
 }
 
+int emul_fft12_roundtrip(const float* zin /*[4096][2]*/, float* slots, float* back) {
+    std::vector<c32> consts;
+    build_consts12(consts);
+    launch(1, [&](HostEnv& env, int) {
+        Lds12 l; l.base = env.lds();
+        load_consts12(env, l, consts.data());
+        c32 v[8];
+        const int tid = env.tid();
+        for (int n1 = 0; n1 < 8; ++n1) v[n1] = mk(zin[2 * (n1 * 512 + tid)], zin[2 * (n1 * 512 + tid) + 1]);
+        int par = 0;
+        fft12_fwd(env, l, v, par);
+        for (int r = 0; r < 8; ++r) { slots[2 * (tid * 8 + r)] = v[r].x; slots[2 * (tid * 8 + r) + 1] = v[r].y; }
+        fft12_inv(env, l, v, par);
+        for (int n1 = 0; n1 < 8; ++n1) { back[2 * (n1 * 512 + tid)] = v[n1].x; back[2 * (n1 * 512 + tid) + 1] = v[n1].y; }
+    }, NT12);
+    return 0;
+}
+
 // mode: 0 fixed (P==1), 1 seg (seg_len[P-1]), 2 explicit (idx,w).  path: 0 = overlap-save, 1 = direct
 int emul_render(const float* x, int64_t T, const float* bank, int P, int C, int L, int mode,
                 const int64_t* seg_len, const int64_t* idx, const float* w, float* y, int path, int64_t* ntasks, int xd) {
+    const bool g12 = (path == 0 && xd == 12);
+    const int BB = g12 ? B12 : B;
     std::vector<c32> consts;
-    build_consts(consts);
-    const int M = (int)((T + B - 1) / B);
-    std::vector<c32> Xs((size_t)(M + 1) * B);
-    if (path == 0) launch(M + 1, [&](HostEnv& env, int m) { xspec_body(env, x, T, consts.data(), Xs.data(), m, M); });
+    if (g12) build_consts12(consts); else build_consts(consts);
+    const int M = (int)((T + BB - 1) / BB);
+    std::vector<c32> Xs((size_t)(M + 1) * BB);
+    if (path == 0 && !g12) launch(M + 1, [&](HostEnv& env, int m) { xspec_body(env, x, T, consts.data(), Xs.data(), m, M); });
+    if (g12) launch(M + 1, [&](HostEnv& env, int m) { xspec12_body(env, x, T, consts.data(), Xs.data(), m, M); }, NT12);
 
     Plan plan;
     std::vector<int64_t> seg_start;
     std::vector<int32_t> bmin, bmax;
-    const int fine = path == 0 ? B / DTILE : 1;
-    const int jmax = path == 0 ? JMAX : 1;
+    const int fine = path == 0 ? BB / DTILE : 1;
+    const int jmax = path == 0 ? (g12 ? JMAX12 : JMAX) : 1;
     if (mode == 0) {
-        build_plan_fixed(T, C, path == 0 ? B : DTILE, jmax, plan);
+        build_plan_fixed(T, C, path == 0 ? BB : DTILE, jmax, plan);
     } else if (mode == 1) {
         seg_start.resize(P);
         int64_t s = 0;
@@ -97,7 +118,7 @@ int emul_render(const float* x, int64_t T, const float* bank, int P, int C, int 
     RenderParams prm;
     std::memset(&prm, 0, sizeof(prm));
     prm.x = x; prm.T = T; prm.bank = bank; prm.P = P; prm.C = C; prm.L = L;
-    prm.NP = (L + B - 1) / B; prm.Xs = Xs.data(); prm.M = M; prm.consts = consts.data();
+    prm.NP = (L + BB - 1) / BB; prm.Xs = Xs.data(); prm.M = M; prm.consts = consts.data();
     prm.mode = mode; prm.seg_start = seg_start.data(); prm.idx = idx; prm.w = w; prm.y = y;
     *ntasks = 0;
     for (int parity = 0; parity < 2; ++parity) {
@@ -107,7 +128,8 @@ int emul_render(const float* x, int64_t T, const float* bank, int P, int C, int 
         *ntasks += (int64_t)plan.tasks[parity].size();
         xcd_interleave(plan.tasks[parity]);
         prm.tasks = plan.tasks[parity].data();
-        if (path == 0 && xd == 0) launch((int)plan.tasks[parity].size(), [&](HostEnv& env, int b) { os_body<HostEnv, 0>(env, prm, b); });
+        if (g12) launch((int)plan.tasks[parity].size(), [&](HostEnv& env, int b) { os12_body(env, prm, b); }, NT12);
+        else if (path == 0 && xd == 0) launch((int)plan.tasks[parity].size(), [&](HostEnv& env, int b) { os_body<HostEnv, 0>(env, prm, b); });
         else if (path == 0 && xd == 2) launch((int)plan.tasks[parity].size(), [&](HostEnv& env, int b) { os_body<HostEnv, 2>(env, prm, b); });
         else if (path == 0) launch((int)plan.tasks[parity].size(), [&](HostEnv& env, int b) { os_body<HostEnv, 3>(env, prm, b); });
         else launch((int)plan.tasks[parity].size(), [&](HostEnv& env, int b) { direct_body(env, prm, b); });
