@@ -15,6 +15,8 @@ LIB_PATH = os.path.join(PKG, "lib", "libsonicsim_hip.so")
 FLAG_DEVICE_PTR = 0x1
 FLAG_PATH_OS = 0x10
 FLAG_PATH_DIRECT = 0x20
+FLAG_GEOM_2048 = 0x40
+FLAG_GEOM_4096 = 0x80
 FLAG_LAYOUT_TC = 0x100
 
 SS_EINVAL, SS_EHIP, SS_ENOMEM, SS_ENODEV = -1, -2, -3, -4

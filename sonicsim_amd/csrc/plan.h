@@ -99,6 +99,20 @@ inline void xcd_interleave(std::vector<Task>& tasks, int nxcd = 8) {
     tasks.swap(out);
 }
 
+// Merge both parity lists into one launch order sorted by descending cost (LPT): with atomic accumulation
+// the rows no longer need two passes.  cost ~ partitions * (fft + nj * mac) + nj * ifft.
+inline void merge_lpt(Plan& plan, int NP, std::vector<Task>& out) {
+    out.clear();
+    out.reserve(plan.tasks[0].size() + plan.tasks[1].size());
+    out.insert(out.end(), plan.tasks[0].begin(), plan.tasks[0].end());
+    out.insert(out.end(), plan.tasks[1].begin(), plan.tasks[1].end());
+    auto cost = [NP](const Task& t) {
+        const int np_eff = std::min(NP, t.j0 + t.nj);
+        return (int64_t)np_eff * (10 + 2 * t.nj) + 12 * (int64_t)t.nj;
+    };
+    std::stable_sort(out.begin(), out.end(), [&](const Task& a, const Task& b) { return cost(a) > cost(b); });
+}
+
 // fixed receiver: one row, every block, store pass only
 inline void build_plan_fixed(int64_t T, int C, int block, int jmax, Plan& plan) {
     plan.tasks[0].clear();

@@ -25,6 +25,12 @@ struct DevEnv {
     c32* smem;
     __device__ __forceinline__ int tid() const { return threadIdx.x; }
     __device__ __forceinline__ void barrier() const { __syncthreads(); }
+    // same-wave LDS hand-off: DS instructions of one wave execute in order, so only the compiler must be
+    // kept from reordering across this point
+    __device__ __forceinline__ void wave_sync() const {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
     __device__ __forceinline__ c32* lds() const { return smem; }
 };
 
@@ -46,15 +52,15 @@ template <int XD, int ABL = 0> __global__ __launch_bounds__(256, 2) void k_os(Re
 
 // geometry 12 (B = 4096, 512 threads, sliding spectrum window): one workgroup per CU
 __global__ __launch_bounds__(512, 2) void k_xspec12(const float* __restrict__ x, int64_t T, const c32* __restrict__ consts,
-                                                    c32* __restrict__ Xs, int M) {
+                                                    c32* __restrict__ Xs, int M, float* __restrict__ yzero, int64_t nzero) {
     __shared__ __attribute__((aligned(16))) c32 smem[LDS12_C32];
     DevEnv env{smem};
-    xspec12_body(env, x, T, consts, Xs, (int)blockIdx.x, M);
+    xspec12_body(env, x, T, consts, Xs, (int)blockIdx.x, M, yzero, nzero);
 }
 template <int ABL = 0> __global__ __launch_bounds__(512, 2) void k_os12(RenderParams prm) {
     __shared__ __attribute__((aligned(16))) c32 smem[LDS12_C32];
     DevEnv env{smem};
-    os12_body<DevEnv, ABL>(env, prm, (int)blockIdx.x);
+    os12_body<DevEnv, ABL>(env, prm, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // direct-form fallback / cross-check
@@ -391,6 +397,8 @@ struct Ctx {
     std::vector<int64_t> seg_start;
     std::vector<int32_t> bmin, bmax;
     Plan plan;
+    std::vector<Task> merged;
+    int num_cu = 0;
 };
 
 std::mutex g_mu;
@@ -417,6 +425,9 @@ int get_ctx(Ctx** out) {
         build_consts12(tab);
         HIPCHK(hipMalloc((void**)&c->consts12, sizeof(c32) * CONST12_C32));
         HIPCHK(hipMemcpy(c->consts12, tab.data(), sizeof(c32) * CONST12_C32, hipMemcpyHostToDevice));
+        hipDeviceProp_t prop;
+        HIPCHK(hipGetDeviceProperties(&prop, dev));
+        c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         if (const char* e = getenv("SS_OS_GEOM")) c->os_geom = atoi(e);
         if (const char* e = getenv("SS_OS_VARIANT")) c->os_variant = atoi(e);
         if (const char* e = getenv("SS_OS_ABLATE")) c->os_ablate = atoi(e);
@@ -543,7 +554,10 @@ int render(int mode, const float* x, int64_t T, const float* bank, int32_t P, in
     bool use_os = L > 128;
     if (flags & SS_FLAG_PATH_OS) use_os = true;
     if (flags & SS_FLAG_PATH_DIRECT) use_os = false;
-    const bool g12 = use_os && (c->os_geom == 12 || (c->os_geom == 0 && L > 2 * B));
+    int geom = c->os_geom;
+    if (flags & SS_FLAG_GEOM_2048) geom = 11;
+    if (flags & SS_FLAG_GEOM_4096) geom = 12;
+    const bool g12 = use_os && T < ((int64_t)1 << 30) && (geom == 12 || (geom == 0 && L > 2 * B));
     const int BB = g12 ? B12 : B;
     const int JM = g12 ? JMAX12 : JMAX;
     const int M = (int)((T + BB - 1) / BB);
@@ -583,6 +597,12 @@ int render(int mode, const float* x, int64_t T, const float* bank, int32_t P, in
     if (c->xcd_order) { xcd_interleave(c->plan.tasks[0]); xcd_interleave(c->plan.tasks[1]); }
 
     // ---- upload plan blob: [seg_start (P int64)][tasks parity 0][tasks parity 1]
+    //      geometry 12: ONE list in LPT order (atomic accumulation, persistent workgroups)
+    if (g12) {
+        merge_lpt(c->plan, NPart, c->merged);
+        c->plan.tasks[0].swap(c->merged);
+        c->plan.tasks[1].clear();
+    }
     const size_t n0 = c->plan.tasks[0].size(), n1 = c->plan.tasks[1].size();
     const size_t seg_bytes = sizeof(int64_t) * (size_t)P;
     const size_t blob = seg_bytes + sizeof(Task) * (n0 + n1);
@@ -608,22 +628,31 @@ int render(int mode, const float* x, int64_t T, const float* bank, int32_t P, in
         prm.Xs = (const c32*)c->ws[WS_XS];
         {
             ProfScope ps(c, stream, 1);
-            if (g12) hipLaunchKernelGGL(k_xspec12, dim3(M + 1), dim3(NT12), 0, stream, dx, T, (const c32*)c->consts12, (c32*)c->ws[WS_XS], M);
+            if (g12) hipLaunchKernelGGL(k_xspec12, dim3(M + 1), dim3(NT12), 0, stream, dx, T, (const c32*)c->consts12, (c32*)c->ws[WS_XS], M,
+                                        dy, (int64_t)C * T);
             else hipLaunchKernelGGL(k_xspec, dim3(M + 1), dim3(NT), 0, stream, dx, T, (const c32*)c->consts, (c32*)c->ws[WS_XS], M);
         }
         HIPCHK(hipGetLastError());
     }
     const Task* dtasks = (const Task*)((const char*)c->ws[WS_PLAN] + seg_bytes);
     for (int parity = 0; parity < 2; ++parity) {
-        const size_t nt = parity ? n1 : n0;
+        size_t nt = parity ? n1 : n0;
         if (!nt) continue;
         prm.tasks = dtasks + (parity ? n0 : 0);
-        prm.accumulate = parity;
+        prm.ntasks = (int32_t)nt;
+        prm.accumulate = g12 ? 2 : parity;
+        if (g12 && nt > (size_t)c->num_cu) nt = (size_t)c->num_cu;     // persistent: one workgroup per CU
         ProfScope ps(c, stream, use_os ? 0 : 2);
         if (!use_os) hipLaunchKernelGGL(k_direct, dim3((unsigned)nt), dim3(NT), 0, stream, prm);
         else if (g12 && c->os_ablate == 1) hipLaunchKernelGGL(k_os12<1>, dim3((unsigned)nt), dim3(NT12), 0, stream, prm);
         else if (g12 && c->os_ablate == 2) hipLaunchKernelGGL(k_os12<2>, dim3((unsigned)nt), dim3(NT12), 0, stream, prm);
         else if (g12 && c->os_ablate == 4) hipLaunchKernelGGL(k_os12<4>, dim3((unsigned)nt), dim3(NT12), 0, stream, prm);
+        else if (g12 && c->os_ablate == 8) hipLaunchKernelGGL(k_os12<8>, dim3((unsigned)nt), dim3(NT12), 0, stream, prm);
+        else if (g12 && c->os_ablate == 16) hipLaunchKernelGGL(k_os12<16>, dim3((unsigned)nt), dim3(NT12), 0, stream, prm);
+        else if (g12 && c->os_ablate == 32) hipLaunchKernelGGL(k_os12<32>, dim3((unsigned)nt), dim3(NT12), 0, stream, prm);
+        else if (g12 && c->os_ablate == 48) hipLaunchKernelGGL(k_os12<48>, dim3((unsigned)nt), dim3(NT12), 0, stream, prm);
+        else if (g12 && c->os_ablate == 56) hipLaunchKernelGGL(k_os12<56>, dim3((unsigned)nt), dim3(NT12), 0, stream, prm);
+        else if (g12 && c->os_ablate == 63) hipLaunchKernelGGL(k_os12<63>, dim3((unsigned)nt), dim3(NT12), 0, stream, prm);
         else if (g12 && c->os_ablate == 7) hipLaunchKernelGGL(k_os12<7>, dim3((unsigned)nt), dim3(NT12), 0, stream, prm);
         else if (g12) hipLaunchKernelGGL(k_os12<0>, dim3((unsigned)nt), dim3(NT12), 0, stream, prm);
         else if (c->os_ablate == 1) hipLaunchKernelGGL((k_os<3, 1>), dim3((unsigned)nt), dim3(NT), 0, stream, prm);

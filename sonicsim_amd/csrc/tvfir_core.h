@@ -80,8 +80,9 @@ struct RenderParams {
     int32_t M;               // ceil(T / B)
     const c32* consts;       // [CONST_C32]
     const Task* tasks;
+    int32_t ntasks;          // persistent kernels iterate over all of them
     int32_t mode;            // CoefMode
-    int32_t accumulate;      // 0: y = contribution (even rows), 1: y += contribution (odd rows)
+    int32_t accumulate;      // 0: y = contribution (even rows), 1: y += contribution (odd rows), 2: atomic add onto zeroed y
     const int64_t* seg_start;  // [P]  COEF_SEG: segment k covers [seg_start[k], seg_start[k+1]); seg_start[P-1] == T
     const int64_t* idx;      // [T]  COEF_EXPLICIT
     const float* w;          // [T]  COEF_EXPLICIT
@@ -348,12 +349,67 @@ SS_HD bool row_coef(const RowCoef& rc, int64_t t, float& coef) {
     return false;
 }
 
+// Block-relative form used by geometry 12: everything per sample is 32-bit (sample offset r inside the
+// block, segment bounds relative to the block start; requires T < 2^30), one int->double conversion, one
+// double multiply, one double->float conversion per sample -- the int64 compares and int64->double
+// conversions of row_coef() cost ~10 % of the whole render when done per sample.
+struct BlockCoef {
+    int32_t mode, row;
+    int32_t A0, A1, A2, TL;   // segment bounds and T, relative to the block start, clamped to +-2^30
+    double inv0, inv1;
+    const int64_t* idx;       // already offset to the block start
+    const float* w;
+};
+SS_HD int32_t rel30(int64_t v) {
+    const int64_t lim = (int64_t)1 << 30;
+    return (int32_t)(v < -lim ? -lim : (v > lim ? lim : v));
+}
+SS_HD BlockCoef make_blockcoef(const RowCoef& rc, int64_t t0, int64_t T) {
+    BlockCoef bc;
+    bc.mode = rc.mode; bc.row = rc.row;
+    bc.A0 = rel30(rc.a0 - t0); bc.A1 = rel30(rc.a1 - t0); bc.A2 = rel30(rc.a2 - t0); bc.TL = rel30(T - t0);
+    bc.inv0 = rc.inv0; bc.inv1 = rc.inv1;
+    bc.idx = rc.idx ? rc.idx + t0 : rc.idx;
+    bc.w = rc.w ? rc.w + t0 : rc.w;
+    return bc;
+}
+SS_HD bool block_coef(const BlockCoef& bc, int32_t r, float& coef) {
+    if (r >= bc.TL) return false;
+    if (bc.mode == COEF_FIXED) { coef = 1.0f; return true; }
+    if (bc.mode == COEF_SEG) {
+        if (r >= bc.A1) {
+            if (r >= bc.A2) return false;
+            coef = 1.0f - (float)((double)(r - bc.A1) * bc.inv1);
+            return true;
+        }
+        if (r < bc.A0) return false;
+        coef = (float)((double)(r - bc.A0) * bc.inv0);
+        return true;
+    }
+    const int64_t k = bc.idx[r];
+    if (k == bc.row) { coef = 1.0f - bc.w[r]; return true; }
+    if (k + 1 == bc.row) { coef = bc.w[r]; return true; }
+    return false;
+}
+
+// Accumulation modes.  Mode 2 (geometry 12): y is zeroed by the spectra kernel and every sample receives
+// exactly TWO hardware float atomic adds (its start row and its end row) -- 0 + a + b is the same bit
+// pattern in either order, so the result stays deterministic while all rows run in ONE launch.
+SS_HD void atomic_add_f32(float* p, float v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    unsafeAtomicAdd(p, v);
+#else
+    *p += v;
+#endif
+}
 SS_HD void emit(const RenderParams& prm, const RowCoef& rc, int chan, int64_t t, float val) {
     float coef;
     if (t < prm.T && row_coef(rc, t, coef)) {
         float* yp = prm.y + (int64_t)chan * prm.T + t;
         const float contrib = coef * val;
-        if (prm.accumulate) *yp = *yp + contrib; else *yp = contrib;
+        if (prm.accumulate == 2) atomic_add_f32(yp, contrib);
+        else if (prm.accumulate) *yp = *yp + contrib;
+        else *yp = contrib;
     }
 }
 
@@ -529,8 +585,9 @@ constexpr int TW2_12 = 3584;     // [7][64]  W_512^(m2*k2)
 constexpr int TW3_12 = 4032;     // [7][8]   W_64^(n4*k3)
 constexpr int TWIST_12 = 4096;   // [4096]   exp(-i pi n / 8192)
 constexpr int CONST12_C32 = 8192;
-constexpr int EX12_C32 = 5120;   // E1: 4096, E2: 64*72 = 4608, E3: 512*10 = 5120
-constexpr int LDS12_C32 = CONST12_C32 + 2 * EX12_C32;   // 18432 c32 = 147456 bytes
+constexpr int C12_C32 = 4096;        // cross-wave exchange buffer (pass 1 -> pass 2)
+constexpr int PRIV12_C32 = 576;      // per-wave private exchange region: E2 8 rows x 72, E3 64 groups x 9
+constexpr int LDS12_C32 = CONST12_C32 + C12_C32 + 8 * PRIV12_C32;   // 16896 c32 = 135168 bytes
 
 struct Lds12 {
     c32* base;
@@ -538,86 +595,99 @@ struct Lds12 {
     SS_HD const c32* tw2() const { return base + TW2_12; }
     SS_HD const c32* tw3() const { return base + TW3_12; }
     SS_HD const c32* twist() const { return base + TWIST_12; }
-    SS_HD c32* exA(int par) const { return base + CONST12_C32 + (par ? EX12_C32 : 0); }
-    SS_HD c32* exB(int par) const { return base + CONST12_C32 + (par ? 0 : EX12_C32); }
+    SS_HD c32* cross() const { return base + CONST12_C32; }
+    SS_HD c32* priv(int wave) const { return base + CONST12_C32 + C12_C32 + wave * PRIV12_C32; }
 };
 
 // Forward 4096-point FFT.  In: v[n1] = z[n1*512 + tid].  Out: slot (tid, r): tid = k1*64 + k2*8 + k3, r = k4,
 // bin = k1 + 8*k2 + 64*k3 + 512*k4.
+//
+// Only pass 1 -> pass 2 crosses waves (wave k1 then owns sub-transform k1: 512 points = 64 lanes x 8).  The
+// later exchanges stay inside the wave's private LDS region and need NO workgroup barrier -- LDS executes
+// one wave's instructions in order -- so the 8 waves drift apart and the two waves sharing a SIMD overlap
+// each other's LDS latency.  Barriers per transform: one RAW (cross buffer written -> read) and one WAR
+// right after the reads (cheap: the waves have just been released together), instead of three.
 template <class Env> SS_HD void fft12_fwd(Env& env, const Lds12& l, c32* v, int& par) {
+    (void)par;
     const int tid = env.tid();
-    c32* A = l.exA(par);
-    c32* Bf = l.exB(par);
-    par ^= 1;
+    c32* C = l.cross();
+    c32* P = l.priv(tid >> 6);
+    const int lane = tid & 63;
     dft8<false>(v);
-    A[tid] = v[0];
+    C[tid] = v[0];
 #pragma unroll
-    for (int k = 1; k < 8; ++k) A[k * 512 + tid] = cmul(v[k], l.tw1()[(k - 1) * 512 + tid]);
+    for (int k = 1; k < 8; ++k) C[k * 512 + tid] = cmul(v[k], l.tw1()[(k - 1) * 512 + tid]);
     env.barrier();
     {
-        const int k1 = tid >> 6, m2 = tid & 63;
+        const int k1 = tid >> 6;
 #pragma unroll
-        for (int n = 0; n < 8; ++n) v[n] = A[k1 * 512 + n * 64 + m2];
+        for (int n = 0; n < 8; ++n) v[n] = C[k1 * 512 + n * 64 + lane];
+        env.barrier();                                   // WAR: the next transform may overwrite C
         dft8<false>(v);
-        Bf[(k1 * 8) * 72 + m2] = v[0];
+        P[lane] = v[0];
 #pragma unroll
-        for (int k = 1; k < 8; ++k) Bf[(k1 * 8 + k) * 72 + m2] = cmul(v[k], l.tw2()[(k - 1) * 64 + m2]);
+        for (int k = 1; k < 8; ++k) P[k * 72 + lane] = cmul(v[k], l.tw2()[(k - 1) * 64 + lane]);
     }
-    env.barrier();
+    env.wave_sync();
     {
-        const int g = tid >> 3, n4 = tid & 7;
+        const int k2 = lane >> 3, n4 = lane & 7;
 #pragma unroll
-        for (int n = 0; n < 8; ++n) v[n] = Bf[g * 72 + n * 8 + n4];
+        for (int n = 0; n < 8; ++n) v[n] = P[k2 * 72 + n * 8 + n4];
         dft8<false>(v);
-        A[(g * 8) * 10 + n4] = v[0];
+        env.wave_sync();                                 // all lanes have read before the region is rewritten
+        P[(k2 * 8) * 9 + n4] = v[0];
 #pragma unroll
-        for (int k = 1; k < 8; ++k) A[(g * 8 + k) * 10 + n4] = cmul(v[k], l.tw3()[(k - 1) * 8 + n4]);
+        for (int k = 1; k < 8; ++k) P[(k2 * 8 + k) * 9 + n4] = cmul(v[k], l.tw3()[(k - 1) * 8 + n4]);
     }
-    env.barrier();
+    env.wave_sync();
     {
-        const c32* p0 = A + tid * 10;
+        const c32* p0 = P + lane * 9;
 #pragma unroll
         for (int n = 0; n < 8; ++n) v[n] = p0[n];
         dft8<false>(v);
     }
+    env.wave_sync();                                     // region free for the next transform of this wave
 }
 
 template <class Env> SS_HD void fft12_inv(Env& env, const Lds12& l, c32* v, int& par) {
+    (void)par;
     const int tid = env.tid();
-    c32* A = l.exA(par);
-    c32* Bf = l.exB(par);
-    par ^= 1;
+    c32* C = l.cross();
+    c32* P = l.priv(tid >> 6);
+    const int lane = tid & 63;
     {
         dft8<true>(v);
-        c32* p0 = A + tid * 10;
+        c32* p0 = P + lane * 9;
 #pragma unroll
         for (int n = 0; n < 8; ++n) p0[n] = v[n];
     }
-    env.barrier();
+    env.wave_sync();
     {
-        const int g = tid >> 3, n4 = tid & 7;
-        v[0] = A[(g * 8) * 10 + n4];
+        const int k2 = lane >> 3, n4 = lane & 7;
+        v[0] = P[(k2 * 8) * 9 + n4];
 #pragma unroll
-        for (int k = 1; k < 8; ++k) v[k] = cmulc(A[(g * 8 + k) * 10 + n4], l.tw3()[(k - 1) * 8 + n4]);
+        for (int k = 1; k < 8; ++k) v[k] = cmulc(P[(k2 * 8 + k) * 9 + n4], l.tw3()[(k - 1) * 8 + n4]);
+        dft8<true>(v);
+        env.wave_sync();
+#pragma unroll
+        for (int n = 0; n < 8; ++n) P[k2 * 72 + n * 8 + n4] = v[n];
+    }
+    env.wave_sync();
+    {
+        const int k1 = tid >> 6;
+        v[0] = P[lane];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) v[k] = cmulc(P[k * 72 + lane], l.tw2()[(k - 1) * 64 + lane]);
         dft8<true>(v);
 #pragma unroll
-        for (int n = 0; n < 8; ++n) Bf[g * 72 + n * 8 + n4] = v[n];
+        for (int n = 0; n < 8; ++n) C[k1 * 512 + n * 64 + lane] = v[n];
     }
     env.barrier();
     {
-        const int k1 = tid >> 6, m2 = tid & 63;
-        v[0] = Bf[(k1 * 8) * 72 + m2];
+        v[0] = C[tid];
 #pragma unroll
-        for (int k = 1; k < 8; ++k) v[k] = cmulc(Bf[(k1 * 8 + k) * 72 + m2], l.tw2()[(k - 1) * 64 + m2]);
-        dft8<true>(v);
-#pragma unroll
-        for (int n = 0; n < 8; ++n) A[k1 * 512 + n * 64 + m2] = v[n];
-    }
-    env.barrier();
-    {
-        v[0] = A[tid];
-#pragma unroll
-        for (int k = 1; k < 8; ++k) v[k] = cmulc(A[k * 512 + tid], l.tw1()[(k - 1) * 512 + tid]);
+        for (int k = 1; k < 8; ++k) v[k] = cmulc(C[k * 512 + tid], l.tw1()[(k - 1) * 512 + tid]);
+        env.barrier();                                   // WAR
         dft8<true>(v);
     }
 }
@@ -629,8 +699,14 @@ template <class Env> SS_HD void load_consts12(Env& env, const Lds12& l, const c3
 }
 
 // input spectra, B = 4096: slot layout c32 index ((r>>1)*512 + tid)*2 + (r&1); Xs[M] = 0
-template <class Env> SS_HD void xspec12_body(Env& env, const float* x, int64_t T, const c32* consts, c32* Xs, int m, int M) {
+template <class Env> SS_HD void xspec12_body(Env& env, const float* x, int64_t T, const c32* consts, c32* Xs, int m, int M,
+                                             float* yzero = nullptr, int64_t nzero = 0) {
     const int tid = env.tid();
+    if (yzero) {   // zero this workgroup's slice of y for the atomic accumulation of the render kernel
+        const int64_t chunk = (nzero + M) / (M + 1);
+        const int64_t lo = (int64_t)m * chunk, hi = lo + chunk < nzero ? lo + chunk : nzero;
+        for (int64_t i = lo + tid; i < hi; i += NT12) yzero[i] = 0.0f;
+    }
     if (m >= M) {
         c32* z = Xs + (int64_t)M * B12;
         for (int i = tid; i < B12; i += NT12) z[i] = mk(0.0f, 0.0f);
@@ -658,105 +734,137 @@ template <class Env> SS_HD void xspec12_body(Env& env, const float* x, int64_t T
     }
 }
 
-// render body, B = 4096, sliding spectrum window in registers
-template <class Env, int ABL = 0> SS_HD void os12_body(Env& env, const RenderParams& prm, int task_id) {
+// render body, B = 4096, sliding spectrum window in registers.
+// One partition step: twist -> forward FFT -> 4 block MACs -> slide the window.
+template <class Env, int ABL> SS_HD void os12_step(Env& env, const Lds12& l, const float* h, int lastn, int p, const f4* nxaddr,
+                                                    float (&hcur)[8], c32 (&acc)[JMAX12][8], f4 (&win)[JMAX12][4], int& par) {
+    const int tid = env.tid();
+    // the one new spectrum the NEXT partition needs (block 0 at step p+1): in flight under this FFT + MAC
+    f4 nx[4];
+    if (ABL & 32) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) nx[q] = win[1][q];
+    } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) nx[q] = nxaddr[q * 512];
+    }
+    c32 v[8];
+#pragma unroll
+    for (int n1 = 0; n1 < 8; ++n1) {
+        const int n = p * B12 + n1 * 512 + tid;
+        const float hv = (n <= lastn) ? hcur[n1] : 0.0f;     // the tail mask is applied at use, never right after the load
+        const c32 tw = l.twist()[n1 * 512 + tid];
+        v[n1] = mk(hv * tw.x, hv * tw.y);
+    }
+    // taps for partition p+2 go into the buffer just consumed (ping-pong with the other buffer): the HBM
+    // latency is covered by two full steps, and no register copy ever waits on an in-flight load
+    if (!(ABL & 16)) {
+#pragma unroll
+        for (int n1 = 0; n1 < 8; ++n1) {
+            const int n = (p + 2) * B12 + n1 * 512 + tid;
+            hcur[n1] = h[n < lastn ? n : lastn];              // clamped address: branch-free, always in bounds
+        }
+    }
+    if (!(ABL & 1)) fft12_fwd(env, l, v, par);
+    if (ABL & 2) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) { SS_KEEP(v[r].x); SS_KEEP(v[r].y); }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { SS_KEEP(nx[q].x); SS_KEEP(nx[q].w); }
+    }
+#pragma unroll
+    for (int j = 0; j < ((ABL & 2) ? 0 : JMAX12); ++j) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            acc[j][2 * q] = cmac(acc[j][2 * q], mk(win[j][q].x, win[j][q].y), v[2 * q]);
+            acc[j][2 * q + 1] = cmac(acc[j][2 * q + 1], mk(win[j][q].z, win[j][q].w), v[2 * q + 1]);
+        }
+    }
+    // slide: block j of the next partition needs what block j-1 used now
+#pragma unroll
+    for (int j = JMAX12 - 1; j > 0; --j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) win[j][q] = win[j - 1][q];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) win[0][q] = nx[q];
+}
+
+// Persistent: workgroup `wg` of `nwg` walks tasks wg, wg+nwg, ... (the host sorts tasks by descending cost,
+// so this static round-robin is an LPT schedule); the 64 KB constant table is loaded into LDS once.
+template <class Env, int ABL = 0> SS_HD void os12_body(Env& env, const RenderParams& prm, int wg, int nwg) {
     Lds12 l; l.base = env.lds();
     load_consts12(env, l, prm.consts);
     const int tid = env.tid();
-    const Task tk = prm.tasks[task_id];
-    if (tk.nj <= 0) return;
-    const float* h = prm.bank + ((int64_t)tk.row * prm.C + tk.chan) * prm.L;
-    const int nj = tk.nj, j0 = tk.j0;
-
-    c32 acc[JMAX12][8];
-#pragma unroll
-    for (int j = 0; j < JMAX12; ++j)
-#pragma unroll
-        for (int r = 0; r < 8; ++r) acc[j][r] = mk(0.0f, 0.0f);
-
-    int np_eff = prm.NP;
-    if (np_eff > j0 + nj) np_eff = j0 + nj;
-
+    int par = 0;
+    const int lastn = prm.L - 1;
     const f4* Xq = reinterpret_cast<const f4*>(prm.Xs) + tid;     // + m*(B12/2) + q*512
     auto xaddr = [&](int m) -> const f4* {
         const int me = (m >= 0 && m < prm.M) ? m : prm.M;         // Xs[M] is the zero spectrum
         return Xq + (int64_t)me * (B12 / 2);
     };
-    // window: win[j] = X_{j0 + j - p} for the current partition p
-    f4 win[JMAX12][4];
-#pragma unroll
-    for (int j = 0; j < JMAX12; ++j) {
-        const f4* a = xaddr(j < nj ? j0 + j : -1);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) win[j][q] = a[q * 512];
-    }
-    float hn[8];
-#pragma unroll
-    for (int n1 = 0; n1 < 8; ++n1) {
-        const int n = n1 * 512 + tid;
-        hn[n1] = (n < prm.L) ? h[n] : 0.0f;
-    }
-    int par = 0;
-    for (int p = 0; p < np_eff; ++p) {
-        // the one new spectrum the NEXT partition needs (block 0 at step p+1): in flight under this FFT + MAC
-        f4 nx[4];
-        {
-            const f4* a = xaddr(j0 - (p + 1));
-#pragma unroll
-            for (int q = 0; q < 4; ++q) nx[q] = a[q * 512];
-        }
-        c32 v[8];
-#pragma unroll
-        for (int n1 = 0; n1 < 8; ++n1) {
-            const c32 tw = l.twist()[n1 * 512 + tid];
-            v[n1] = mk(hn[n1] * tw.x, hn[n1] * tw.y);
-        }
-        if (p + 1 < np_eff) {
-#pragma unroll
-            for (int n1 = 0; n1 < 8; ++n1) {
-                const int n = (p + 1) * B12 + n1 * 512 + tid;
-                hn[n1] = (n < prm.L) ? h[n] : 0.0f;
-            }
-        }
-        if (!(ABL & 1)) fft12_fwd(env, l, v, par);
-        if (ABL & 2) {
-#pragma unroll
-            for (int r = 0; r < 8; ++r) { SS_KEEP(v[r].x); SS_KEEP(v[r].y); }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) { SS_KEEP(nx[q].x); SS_KEEP(nx[q].w); }
-        }
-#pragma unroll
-        for (int j = 0; j < ((ABL & 2) ? 0 : JMAX12); ++j) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                acc[j][2 * q] = cmac(acc[j][2 * q], mk(win[j][q].x, win[j][q].y), v[2 * q]);
-                acc[j][2 * q + 1] = cmac(acc[j][2 * q + 1], mk(win[j][q].z, win[j][q].w), v[2 * q + 1]);
-            }
-        }
-        // slide: block j of the next partition needs what block j-1 used now
-#pragma unroll
-        for (int j = JMAX12 - 1; j > 0; --j)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) win[j][q] = win[j - 1][q];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) win[0][q] = nx[q];
-    }
+    for (int task_id = wg; task_id < prm.ntasks; task_id += nwg) {
+        const Task tk = prm.tasks[task_id];
+        if (tk.nj <= 0) continue;
+        const float* h = prm.bank + ((int64_t)tk.row * prm.C + tk.chan) * prm.L;
+        const int nj = tk.nj, j0 = tk.j0;
 
-    const RowCoef rc = make_rowcoef(prm, tk.row);
-    const float scale = 1.0f / (float)B12;
+        c32 acc[JMAX12][8];
 #pragma unroll
-    for (int j = 0; j < JMAX12; ++j) {
-        if (j < nj) {
-            c32 v[8];
+        for (int j = 0; j < JMAX12; ++j)
 #pragma unroll
-            for (int r = 0; r < 8; ++r) v[r] = acc[j][r];
-            if (!(ABL & 4)) fft12_inv(env, l, v, par);
+            for (int r = 0; r < 8; ++r) acc[j][r] = mk(0.0f, 0.0f);
+
+        // partitions p > j0+nj-1 only meet windows before t=0 (all zero): skip them
+        int np_eff = prm.NP;
+        if (np_eff > j0 + nj) np_eff = j0 + nj;
+
+        // window: win[j] = X_{j0 + j - p} for the current partition p
+        f4 win[JMAX12][4];
+#pragma unroll
+        for (int j = 0; j < JMAX12; ++j) {
+            const f4* a = xaddr(j < nj ? j0 + j : -1);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) win[j][q] = a[q * 512];
+        }
+        float hA[8], hB[8];
+        if (ABL & 16) {
+#pragma unroll
+            for (int n1 = 0; n1 < 8; ++n1) hA[n1] = hB[n1] = 0.25f * (float)(tid + n1);
+        } else {
 #pragma unroll
             for (int n1 = 0; n1 < 8; ++n1) {
-                const int n = n1 * 512 + tid;
-                const c32 tw = l.twist()[n];
-                const float val = (v[n1].x * tw.y - v[n1].y * tw.x) * scale;
-                emit(prm, rc, tk.chan, (int64_t)(j0 + j) * B12 + n, val);
+                const int na = n1 * 512 + tid, nb = B12 + n1 * 512 + tid;
+                hA[n1] = h[na < lastn ? na : lastn];
+                hB[n1] = h[nb < lastn ? nb : lastn];
+            }
+        }
+        // two partitions per trip (ping-pong tap buffers); an odd count runs one extra all-zero-tap step
+        for (int p = 0; p < np_eff; p += 2) {
+            os12_step<Env, ABL>(env, l, h, lastn, p, xaddr(j0 - (p + 1)), hA, acc, win, par);
+            if (p + 1 < np_eff) os12_step<Env, ABL>(env, l, h, lastn, p + 1, xaddr(j0 - (p + 2)), hB, acc, win, par);
+        }
+
+        const RowCoef rc = make_rowcoef(prm, tk.row);
+        const float scale = 1.0f / (float)B12;
+#pragma unroll
+        for (int j = 0; j < JMAX12; ++j) {
+            if (j < nj) {
+                c32 v[8];
+#pragma unroll
+                for (int r = 0; r < 8; ++r) v[r] = acc[j][r];
+                if (!(ABL & 4)) fft12_inv(env, l, v, par);
+                const int64_t t0 = (int64_t)(j0 + j) * B12;
+                const BlockCoef bc = make_blockcoef(rc, t0, prm.T);
+                float* yb = prm.y + (int64_t)tk.chan * prm.T + t0;
+#pragma unroll
+                for (int n1 = 0; n1 < 8; ++n1) {
+                    const int n = n1 * 512 + tid;
+                    const c32 tw = l.twist()[n];
+                    const float val = (v[n1].x * tw.y - v[n1].y * tw.x) * scale;   // -Im(z * conj(tw)) / B
+                    float coef;
+                    if (ABL & 8) SS_KEEP(val);
+                    else if (block_coef(bc, n, coef)) atomic_add_f32(yb + n, coef * val);
+                }
             }
         }
     }

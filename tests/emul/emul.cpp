@@ -19,6 +19,7 @@ struct HostEnv {
     c32* lds_;
     int tid() const { return tid_; }
     void barrier() const { bar->arrive_and_wait(); }
+    void wave_sync() const { bar->arrive_and_wait(); }   // host threads are not lock-step: use the full barrier
     c32* lds() const { return lds_; }
 };
 
@@ -88,7 +89,7 @@ int emul_render(const float* x, int64_t T, const float* bank, int P, int C, int 
     const int M = (int)((T + BB - 1) / BB);
     std::vector<c32> Xs((size_t)(M + 1) * BB);
     if (path == 0 && !g12) launch(M + 1, [&](HostEnv& env, int m) { xspec_body(env, x, T, consts.data(), Xs.data(), m, M); });
-    if (g12) launch(M + 1, [&](HostEnv& env, int m) { xspec12_body(env, x, T, consts.data(), Xs.data(), m, M); }, NT12);
+    if (g12) launch(M + 1, [&](HostEnv& env, int m) { xspec12_body(env, x, T, consts.data(), Xs.data(), m, M, y, (int64_t)C * T); }, NT12);
 
     Plan plan;
     std::vector<int64_t> seg_start;
@@ -121,6 +122,17 @@ int emul_render(const float* x, int64_t T, const float* bank, int P, int C, int 
     prm.NP = (L + BB - 1) / BB; prm.Xs = Xs.data(); prm.M = M; prm.consts = consts.data();
     prm.mode = mode; prm.seg_start = seg_start.data(); prm.idx = idx; prm.w = w; prm.y = y;
     *ntasks = 0;
+    if (g12) {   // single persistent launch, atomic accumulation onto the zeroed y, LPT task order
+        std::vector<Task> all;
+        merge_lpt(plan, prm.NP, all);
+        prm.tasks = all.data();
+        prm.ntasks = (int)all.size();
+        prm.accumulate = 2;
+        *ntasks = (int64_t)all.size();
+        const int nwg = std::min<int>(prm.ntasks, 5);
+        launch(nwg, [&](HostEnv& env, int b) { os12_body(env, prm, b, nwg); }, NT12);
+        return 0;
+    }
     for (int parity = 0; parity < 2; ++parity) {
         if (plan.tasks[parity].empty()) continue;
         prm.tasks = plan.tasks[parity].data();
@@ -128,8 +140,7 @@ int emul_render(const float* x, int64_t T, const float* bank, int P, int C, int 
         *ntasks += (int64_t)plan.tasks[parity].size();
         xcd_interleave(plan.tasks[parity]);
         prm.tasks = plan.tasks[parity].data();
-        if (g12) launch((int)plan.tasks[parity].size(), [&](HostEnv& env, int b) { os12_body(env, prm, b); }, NT12);
-        else if (path == 0 && xd == 0) launch((int)plan.tasks[parity].size(), [&](HostEnv& env, int b) { os_body<HostEnv, 0>(env, prm, b); });
+        if (path == 0 && xd == 0) launch((int)plan.tasks[parity].size(), [&](HostEnv& env, int b) { os_body<HostEnv, 0>(env, prm, b); });
         else if (path == 0 && xd == 2) launch((int)plan.tasks[parity].size(), [&](HostEnv& env, int b) { os_body<HostEnv, 2>(env, prm, b); });
         else if (path == 0) launch((int)plan.tasks[parity].size(), [&](HostEnv& env, int b) { os_body<HostEnv, 3>(env, prm, b); });
         else launch((int)plan.tasks[parity].size(), [&](HostEnv& env, int b) { direct_body(env, prm, b); });

@@ -44,6 +44,23 @@ def render(lib, x, bank, mode, seg=None, idx=None, w=None, path=0, xd=3):
     return y, nt.value
 
 
+def test_fft4096_slot_mapping(emul):
+    rng = np.random.default_rng(1)
+    N = 4096
+    z = (rng.standard_normal(N) + 1j * rng.standard_normal(N)).astype(np.complex64)
+    zin = np.ascontiguousarray(np.stack([z.real, z.imag], 1).astype(np.float32))
+    slots = np.zeros((N, 2), np.float32)
+    back = np.zeros((N, 2), np.float32)
+    emul.emul_fft12_roundtrip(P(zin), P(slots), P(back))
+    Z = np.fft.fft(z.astype(np.complex128))
+    tid, r = np.arange(N) // 8, np.arange(N) % 8
+    bins = (tid >> 6) + 8 * ((tid >> 3) & 7) + 64 * (tid & 7) + 512 * r
+    assert len(set(bins)) == N
+    S = slots[:, 0] + 1j * slots[:, 1]
+    assert np.abs(S - Z[bins]).max() / np.abs(Z).max() < 1e-6
+    assert np.abs((back[:, 0] + 1j * back[:, 1]) / N - z).max() < 5e-6
+
+
 def test_fft_slot_mapping(emul):
     rng = np.random.default_rng(0)
     z = (rng.standard_normal(2048) + 1j * rng.standard_normal(2048)).astype(np.complex64)
@@ -61,24 +78,28 @@ def test_fft_slot_mapping(emul):
     assert np.abs((back[:, 0] + 1j * back[:, 1]) / 2048 - z).max() < 5e-6
 
 
-@pytest.mark.parametrize("path", [0, 1])
-def test_kernel_bodies_against_reference_goldens(emul, path):
+@pytest.mark.parametrize("path,xd", [(0, 3), (0, 12), (1, 0)])
+def test_kernel_bodies_against_reference_goldens(emul, path, xd):
+    """path 0 = overlap-save (xd 3: B=2048 two-pass geometry, xd 12: B=4096 persistent/atomic geometry), 1 = direct."""
+    import functools
+    global render
+    render_ = functools.partial(render, xd=xd)
     g = golden("g4_moving_small.npz")
     seg = np.bincount(g["idx"], minlength=g["bank"].shape[0] - 1)
-    y, _ = render(emul, g["x"], g["bank"], 1, seg=seg, path=path)
+    y, _ = render_(emul, g["x"], g["bank"], 1, seg=seg, path=path)
     assert_parity(y, g["y"], tol=1e-5)
-    y2, _ = render(emul, g["x"], g["bank"], 2, idx=g["idx"], w=g["w"], path=path)
+    y2, _ = render_(emul, g["x"], g["bank"], 2, idx=g["idx"], w=g["w"], path=path)
     assert np.array_equal(y, y2)            # implicit ramp == explicit (idx, w), bit for bit
     g = golden("g8_arbitrary_idx.npz")
-    y, _ = render(emul, g["x"], g["bank"], 2, idx=g["idx"], w=g["w"], path=path)
+    y, _ = render_(emul, g["x"], g["bank"], 2, idx=g["idx"], w=g["w"], path=path)
     assert_parity(y, g["y"], tol=1e-5)
     g = golden("g1_fixed_cfg1.npz")
-    y, _ = render(emul, g["x"], g["h"][None], 0, path=path)
+    y, _ = render_(emul, g["x"], g["h"][None], 0, path=path)
     assert_parity(y, g["y"], tol=1e-5)
     g = golden("g6_edges.npz")
-    y, _ = render(emul, g["x"], g["bank"], 2, idx=g["idx"], w=g["w"], path=path)
+    y, _ = render_(emul, g["x"], g["bank"], 2, idx=g["idx"], w=g["w"], path=path)
     assert_parity(y, g["y"], tol=1e-5)
-    y, _ = render(emul, g["x1"], g["bank1"], 2, idx=g["idx1"], w=g["w1"], path=path)
+    y, _ = render_(emul, g["x1"], g["bank1"], 2, idx=g["idx1"], w=g["w1"], path=path)
     assert_parity(y, g["y1"], tol=1e-5)
 
 
@@ -90,6 +111,7 @@ def test_zero_length_segments_and_every_sample_written(emul):
     from oracle import moving
     idx, w = moving.expand_segments(seg)
     ref = moving.convolve_moving_receiver(x, bank, idx, w)
-    y, _ = render(emul, x, bank, 1, seg=seg, path=0)
-    assert not np.isnan(y).any()
-    assert_parity(y, ref, tol=1e-5)
+    for xd in (3, 12):
+        y, _ = render(emul, x, bank, 1, seg=seg, path=0, xd=xd)
+        assert not np.isnan(y).any()
+        assert_parity(y, ref, tol=1e-5)

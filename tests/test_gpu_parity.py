@@ -16,7 +16,7 @@ def _seg(idx, P):
     return np.bincount(idx, minlength=P - 1).astype(np.int64)
 
 
-@pytest.mark.parametrize("path", ["os", "direct"])
+@pytest.mark.parametrize("path", ["os2048", "os4096", "direct"])
 def test_goldens_host_pointers(gpu, path):
     from sonicsim_amd import ops
     g = golden("g1_fixed_cfg1.npz")                      # BASELINE config 1 (static, mono, 1 s, 4096 taps)
@@ -43,6 +43,8 @@ def test_golden_medium_device_pointers(gpu):
     y = ops.convolve_moving_seg(xd, bd, g["seg_len"])
     assert y.is_cuda and y.shape == (3, 65536)
     assert_parity(y.cpu().numpy(), g["y"])
+    for path in ("os2048", "os4096"):
+        assert_parity(ops.convolve_moving_seg(xd, bd, g["seg_len"], path=path).cpu().numpy(), g["y"])
     idx, w = moving.expand_segments(g["seg_len"])
     y2 = ops.convolve_moving(xd, bd, torch.from_numpy(idx).to(gpu), torch.from_numpy(w).to(gpu))
     assert torch.equal(y, y2)
@@ -81,11 +83,11 @@ def test_oracle_seeded_shapes(gpu, T, P, C, L, seed):
     np.random.seed(seed)
     idx, w = moving.setup_dynamic_interp(pos, T)
     ref = moving.convolve_moving_receiver(x, bank, idx, w)
-    for path in ("os", "direct"):
+    for path in ("os2048", "os4096", "direct"):
         assert_parity(ops.convolve_moving(x, bank, idx, w, path=path), ref)
         assert_parity(ops.convolve_moving_seg(x, bank, _seg(idx, P), path=path), ref)
     href = moving.convolve_fixed_receiver(x, bank[0])
-    for path in ("os", "direct"):
+    for path in ("os2048", "os4096", "direct"):
         assert_parity(ops.convolve_fixed(x, bank[0], path=path), href)
 
 
@@ -98,7 +100,7 @@ def test_zero_length_segments_and_ragged(gpu):
         seg = np.array(seg)
         idx, w = moving.expand_segments(seg)
         ref = moving.convolve_moving_receiver(x, bank, idx, w)
-        for path in ("os", "direct"):
+        for path in ("os2048", "os4096", "direct"):
             y = ops.convolve_moving_seg(x, bank, seg, path=path)
             assert_parity(y, ref)
 
@@ -204,6 +206,10 @@ def test_full_size_config2(gpu):
     n5 = int(seg[:5].sum())
     ref = moving.convolve_moving_receiver(sc.x[:n5], bank_h[:6], idx[:n5], w[:n5])
     assert_parity(yh[:, :n5], ref)
+    # (b2) the two transform geometries (different FFT sizes, block grids and accumulation schemes) agree
+    y11 = ops.convolve_moving_seg(x, bank, seg, path="os2048").cpu().numpy()
+    y12 = ops.convolve_moving_seg(x, bank, seg, path="os4096").cpu().numpy()
+    assert rel_rms(y11, y12) < 2e-6 and np.array_equal(y12, yh)
     # (c) linearity at full size: render(2x) == 2 render(x) bit-exactly (power-of-two scaling)
     y2 = ops.convolve_moving_seg(2 * x, bank, seg)
     assert torch.equal(y2, 2 * y)
