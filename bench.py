@@ -139,10 +139,11 @@ def main():
         bytes_per_launch = render_bytes / max(1.0, launches_per_render)
         achieved = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
         traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
+        pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")     # written by tools/profile.sh (separate --pmc passes)
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get("k_os", {}).get("hbm_bytes_per_launch")
+                js = json.load(open(pmc))
+                traffic = (js.get("k_os12") or js.get("k_os") or {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         out = {
@@ -165,7 +166,7 @@ def main():
                        "gather": bool(world > 1 and not args.no_gather)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "k_os (row-stationary partitioned overlap-save, one parity pass per launch)",
+                         "kernel": "k_os12 (row-stationary partitioned overlap-save, B=4096, persistent, one launch per render)",
                          "algorithmic_bytes_per_render": render_bytes, "launches_per_render": launches_per_render,
                          "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_ms": avg_launch_ms,
                          "xspec_avg_launch_ms": ms_xs / max(1, n_xs),

@@ -14,6 +14,7 @@ default and ``allow_many_channels=True`` selects BS.1770 with unit channel weigh
 """
 from __future__ import annotations
 
+import functools
 import itertools
 import math
 import typing as T
@@ -92,14 +93,19 @@ def k_weighting_coefficients(rate: float) -> np.ndarray:
     return np.array(rows, dtype=np.float64)
 
 
+@functools.lru_cache(maxsize=64)
 def gating_blocks(num_samples: int, rate: float, block_size: float):
-    """Block bounds exactly as pyloudnorm forms them (float64 product truncated by int())."""
+    """Block bounds exactly as pyloudnorm forms them: ``int(T_g * (j * step) * rate)`` and
+    ``int(T_g * (j * step + 1) * rate)`` -- the same float64 products, evaluated elementwise, then truncated."""
     step = 1.0 - 0.75
     duration = num_samples / rate
     count = int(np.round(((duration - block_size) / (block_size * step))) + 1)
-    lo = [int(block_size * (j * step) * rate) for j in np.arange(0, count)]
-    hi = [int(block_size * (j * step + 1) * rate) for j in np.arange(0, count)]
-    return np.array(lo, dtype=np.int64), np.array(hi, dtype=np.int64)
+    j = np.arange(0, max(count, 0))
+    lo = (block_size * (j * step) * rate).astype(np.int64)
+    hi = (block_size * (j * step + 1) * rate).astype(np.int64)
+    lo.setflags(write=False)
+    hi.setflags(write=False)
+    return lo, hi
 
 
 def _gated_loudness(z: np.ndarray, weights) -> float:
@@ -118,8 +124,10 @@ def _gated_loudness(z: np.ndarray, weights) -> float:
         return float("-inf")
 
 
-def integrated_loudness(data, rate: float, block_size: float = 0.4, allow_many_channels: bool = False) -> float:
-    """pyloudnorm ``Meter(rate, block_size=...).integrated_loudness(data)``; data (T,) or (T, C)."""
+def integrated_loudness(data, rate: float, block_size: float = 0.4, allow_many_channels: bool = False,
+                        channel_first: bool = False) -> float:
+    """pyloudnorm ``Meter(rate, block_size=...).integrated_loudness(data)``; data (T,) or (T, C).
+    ``channel_first=True`` (extension) takes (C, T) -- the layout the renderer produces -- without a transpose."""
     is_t = hasattr(data, "dtype") and str(data.dtype).startswith("torch")
     if not is_t:
         data = np.asarray(data)
@@ -128,22 +136,27 @@ def integrated_loudness(data, rate: float, block_size: float = 0.4, allow_many_c
     ndim = data.ndim
     if ndim > 2:
         raise ValueError("Audio must be 1D or 2D.")
-    n = data.shape[0]
-    nch = 1 if ndim == 1 else data.shape[1]
+    if channel_first and ndim == 2:
+        n, nch = data.shape[1], data.shape[0]
+    else:
+        n = data.shape[0]
+        nch = 1 if ndim == 1 else data.shape[1]
     if nch > 5 and not allow_many_channels:
         raise ValueError("Audio must have five channels or less.")
     if n < block_size * rate:
         raise ValueError("Audio must have length greater than the block size.")
     lo, hi = gating_blocks(n, rate, block_size)
-    z = ops.kweighted_block_power(data, k_weighting_coefficients(rate), lo, hi, block_size * rate, layout_tc=True)
+    z = ops.kweighted_block_power(data, k_weighting_coefficients(rate), lo, hi, block_size * rate,
+                                  layout_tc=not (channel_first and ndim == 2))
     weights = G_WEIGHTS if nch <= 5 else (1.0,) * nch
     return _gated_loudness(z, weights)
 
 
-def lufs_norm(data, sr, norm=-6, allow_many_channels: bool = False):
+def lufs_norm(data, sr, norm=-6, allow_many_channels: bool = False, channel_first: bool = False):
     """SonicSim_audio.py:68-81.  data (T, C) (or (T,)).  Returns (normalised data, gain)."""
-    block_size = 0.4 if len(data) / sr >= 0.4 else len(data) / sr
-    loudness = integrated_loudness(data, sr, block_size, allow_many_channels=allow_many_channels)
+    nsamp = data.shape[-1] if (channel_first and data.ndim == 2) else len(data)
+    block_size = 0.4 if nsamp / sr >= 0.4 else nsamp / sr
+    loudness = integrated_loudness(data, sr, block_size, allow_many_channels=allow_many_channels, channel_first=channel_first)
     if math.isinf(loudness):
         loudness = -40
         print("loudness is inf")
@@ -153,10 +166,10 @@ def lufs_norm(data, sr, norm=-6, allow_many_channels: bool = False):
     return norm_data, gain
 
 
-def get_lufs_norm_audio(audio, sr=16000, lufs=-6, allow_many_channels: bool = False):
+def get_lufs_norm_audio(audio, sr=16000, lufs=-6, allow_many_channels: bool = False, channel_first: bool = False):
     """SonicSim_audio.py:83-86: target drawn from the GLOBAL NumPy RNG, U(lufs-2, lufs+2)."""
     class_lufs = np.random.uniform(lufs - 2, lufs + 2)
-    return lufs_norm(data=audio, sr=sr, norm=class_lufs, allow_many_channels=allow_many_channels)
+    return lufs_norm(data=audio, sr=sr, norm=class_lufs, allow_many_channels=allow_many_channels, channel_first=channel_first)
 
 
 # ----------------------------------------------------------------------------- row X

@@ -271,8 +271,10 @@ __global__ __launch_bounds__(256) void k_scale(const float* __restrict__ in, flo
 struct KwCoef {
     double b[2][3], a[2][3];
     double Mx[16];   // state transition over one full chunk (row-major 4x4)
+    double Mg[16];   // state transition over one full group of KW_GROUP chunks
 };
-constexpr int KW_CHUNK = 1024;
+constexpr int KW_CHUNK = 128;    // samples per thread in the sample-level passes
+constexpr int KW_GROUP = 128;    // chunks per thread in the chunk-level scan
 
 __device__ __forceinline__ double kw_step(const KwCoef& k, double s[4], double xin) {
     const double y1 = k.b[0][0] * xin + s[0];
@@ -283,42 +285,76 @@ __device__ __forceinline__ double kw_step(const KwCoef& k, double s[4], double x
     s[3] = k.b[1][2] * y1 - k.a[1][2] * y2;
     return y2;
 }
+__device__ __forceinline__ void kw_matvec(const double* M, const double s[4], double o[4]) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[r] = M[r * 4 + 0] * s[0] + M[r * 4 + 1] * s[1] + M[r * 4 + 2] * s[2] + M[r * 4 + 3] * s[3];
+}
 
-__global__ __launch_bounds__(64) void k_kw_state(const float* __restrict__ audio, int64_t T, int C, int64_t st, int64_t sc,
-                                                 KwCoef k, int nchunks, double* __restrict__ states /*[C][nchunks][4]*/) {
-    const int id = blockIdx.x * 64 + threadIdx.x;
+// pass 1: zero-state response of every chunk -> its end state z
+__global__ __launch_bounds__(256) void k_kw_state(const float* __restrict__ audio, int64_t T, int C, int64_t st, int64_t sc,
+                                                  KwCoef k, int nchunks, double* __restrict__ states /*[C][nchunks][4]*/) {
+    const int id = blockIdx.x * 256 + threadIdx.x;
     if (id >= C * nchunks) return;
     const int c = id / nchunks, ch = id - c * nchunks;
     double s[4] = {0, 0, 0, 0};
     const int64_t t0 = (int64_t)ch * KW_CHUNK;
     const int64_t t1 = t0 + KW_CHUNK < T ? t0 + KW_CHUNK : T;
-    for (int64_t t = t0; t < t1; ++t) kw_step(k, s, (double)audio[t * st + c * sc]);
+    const float* a = audio + c * sc;
+#pragma unroll 8
+    for (int64_t t = t0; t < t1; ++t) kw_step(k, s, (double)a[t * st]);
     double* o = states + ((int64_t)c * nchunks + ch) * 4;
     o[0] = s[0]; o[1] = s[1]; o[2] = s[2]; o[3] = s[3];
 }
-__global__ void k_kw_scan(KwCoef k, int C, int nchunks, double* __restrict__ states) {
+// pass 2 (MODE 0): per group of KW_GROUP chunks, from a zero group state: end state of the group.
+// pass 4 (MODE 1): same walk from the TRUE group start state: states[] := start state of every chunk.
+template <int MODE>
+__global__ __launch_bounds__(64) void k_kw_groups(KwCoef k, int C, int nchunks, int ngroups, double* __restrict__ states,
+                                                  double* __restrict__ gstate /*[C][ngroups][4]*/) {
+    const int id = blockIdx.x * 64 + threadIdx.x;
+    if (id >= C * ngroups) return;
+    const int c = id / ngroups, g = id - c * ngroups;
+    double s[4] = {0, 0, 0, 0};
+    double* gs = gstate + ((int64_t)c * ngroups + g) * 4;
+    if (MODE == 1) { s[0] = gs[0]; s[1] = gs[1]; s[2] = gs[2]; s[3] = gs[3]; }
+    const int c0 = g * KW_GROUP, c1 = c0 + KW_GROUP < nchunks ? c0 + KW_GROUP : nchunks;
+    for (int ch = c0; ch < c1; ++ch) {
+        double* z = states + ((int64_t)c * nchunks + ch) * 4;
+        const double z0 = z[0], z1 = z[1], z2 = z[2], z3 = z[3];
+        if (MODE == 1) { z[0] = s[0]; z[1] = s[1]; z[2] = s[2]; z[3] = s[3]; }
+        double nx[4];
+        kw_matvec(k.Mx, s, nx);
+        s[0] = nx[0] + z0; s[1] = nx[1] + z1; s[2] = nx[2] + z2; s[3] = nx[3] + z3;
+    }
+    if (MODE == 0) { gs[0] = s[0]; gs[1] = s[1]; gs[2] = s[2]; gs[3] = s[3]; }
+}
+// pass 3: serial over the (few) groups of each channel: gstate[] := start state of every group
+__global__ void k_kw_scan_groups(KwCoef k, int C, int ngroups, double* __restrict__ gstate) {
     const int c = threadIdx.x;
     if (c >= C) return;
     double s[4] = {0, 0, 0, 0};
-    for (int ch = 0; ch < nchunks; ++ch) {
-        double* z = states + ((int64_t)c * nchunks + ch) * 4;
+    for (int g = 0; g < ngroups; ++g) {
+        double* z = gstate + ((int64_t)c * ngroups + g) * 4;
         const double z0 = z[0], z1 = z[1], z2 = z[2], z3 = z[3];
-        z[0] = s[0]; z[1] = s[1]; z[2] = s[2]; z[3] = s[3];     // initial state of this chunk
+        z[0] = s[0]; z[1] = s[1]; z[2] = s[2]; z[3] = s[3];
         double nx[4];
-        for (int r = 0; r < 4; ++r) nx[r] = k.Mx[r * 4 + 0] * s[0] + k.Mx[r * 4 + 1] * s[1] + k.Mx[r * 4 + 2] * s[2] + k.Mx[r * 4 + 3] * s[3];
+        kw_matvec(k.Mg, s, nx);
         s[0] = nx[0] + z0; s[1] = nx[1] + z1; s[2] = nx[2] + z2; s[3] = nx[3] + z3;
     }
 }
-__global__ __launch_bounds__(64) void k_kw_apply(const float* __restrict__ audio, int64_t T, int C, int64_t st, int64_t sc, KwCoef k,
-                                                 int nchunks, const double* __restrict__ states, double* __restrict__ filt /*[C][T]*/) {
-    const int id = blockIdx.x * 64 + threadIdx.x;
+// pass 5: re-run every chunk from its true start state, write the K-weighted signal (float64, [C][T])
+__global__ __launch_bounds__(256) void k_kw_apply(const float* __restrict__ audio, int64_t T, int C, int64_t st, int64_t sc, KwCoef k,
+                                                  int nchunks, const double* __restrict__ states, double* __restrict__ filt /*[C][T]*/) {
+    const int id = blockIdx.x * 256 + threadIdx.x;
     if (id >= C * nchunks) return;
     const int c = id / nchunks, ch = id - c * nchunks;
     const double* z = states + ((int64_t)c * nchunks + ch) * 4;
     double s[4] = {z[0], z[1], z[2], z[3]};
     const int64_t t0 = (int64_t)ch * KW_CHUNK;
     const int64_t t1 = t0 + KW_CHUNK < T ? t0 + KW_CHUNK : T;
-    for (int64_t t = t0; t < t1; ++t) filt[(int64_t)c * T + t] = kw_step(k, s, (double)audio[t * st + c * sc]);
+    const float* a = audio + c * sc;
+    double* f = filt + (int64_t)c * T;
+#pragma unroll 8
+    for (int64_t t = t0; t < t1; ++t) f[t] = kw_step(k, s, (double)a[t * st]);
 }
 __global__ __launch_bounds__(256) void k_block_power(const double* __restrict__ filt, int64_t T, const int64_t* __restrict__ lo,
                                                      const int64_t* __restrict__ hi, int nblocks, double inv_norm,
@@ -946,8 +982,23 @@ int ss_kweighted_block_power_f32(const float* audio, int64_t T, int32_t C, const
         }
         for (int r = 0; r < 4; ++r) k.Mx[r * 4 + u] = s[r];
     }
+    {   // Mg = Mx ^ KW_GROUP by repeated multiplication (KW_GROUP is a power of two: 7 squarings)
+        double A[16], Bm[16];
+        memcpy(A, k.Mx, sizeof(A));
+        for (int g = KW_GROUP; g > 1; g >>= 1) {
+            for (int r = 0; r < 4; ++r)
+                for (int q = 0; q < 4; ++q) {
+                    double acc = 0;
+                    for (int m = 0; m < 4; ++m) acc += A[r * 4 + m] * A[m * 4 + q];
+                    Bm[r * 4 + q] = acc;
+                }
+            memcpy(A, Bm, sizeof(A));
+        }
+        memcpy(k.Mg, A, sizeof(A));
+    }
     const int nchunks = (int)((T + KW_CHUNK - 1) / KW_CHUNK);
-    if ((rc = ws_ensure(c, WS_SCR, sizeof(double) * 4 * (size_t)C * nchunks))) return rc;
+    const int ngroups = (nchunks + KW_GROUP - 1) / KW_GROUP;
+    if ((rc = ws_ensure(c, WS_SCR, sizeof(double) * 4 * ((size_t)C * nchunks + (size_t)C * ngroups)))) return rc;
     if ((rc = ws_ensure(c, WS_FILT, sizeof(double) * (size_t)C * T))) return rc;
     const size_t bb = sizeof(int64_t) * (size_t)nblocks;
     if ((rc = ws_ensure(c, WS_META, 2 * bb))) return rc;
@@ -960,11 +1011,14 @@ int ss_kweighted_block_power_f32(const float* audio, int64_t T, int32_t C, const
     HIPCHK(hipEventRecord(pin->ev, stream));
     pin->pending = true;
     const int nthreads = C * nchunks;
-    hipLaunchKernelGGL(k_kw_state, dim3((nthreads + 63) / 64), dim3(64), 0, stream, (const float*)da, T, C, st, sc, k, nchunks,
-                       (double*)c->ws[WS_SCR]);
-    hipLaunchKernelGGL(k_kw_scan, dim3(1), dim3(64), 0, stream, k, C, nchunks, (double*)c->ws[WS_SCR]);
-    hipLaunchKernelGGL(k_kw_apply, dim3((nthreads + 63) / 64), dim3(64), 0, stream, (const float*)da, T, C, st, sc, k, nchunks,
-                       (const double*)c->ws[WS_SCR], (double*)c->ws[WS_FILT]);
+    double* states = (double*)c->ws[WS_SCR];
+    double* gstate = states + 4 * (size_t)C * nchunks;
+    hipLaunchKernelGGL(k_kw_state, dim3((nthreads + 255) / 256), dim3(256), 0, stream, (const float*)da, T, C, st, sc, k, nchunks, states);
+    hipLaunchKernelGGL(k_kw_groups<0>, dim3((C * ngroups + 63) / 64), dim3(64), 0, stream, k, C, nchunks, ngroups, states, gstate);
+    hipLaunchKernelGGL(k_kw_scan_groups, dim3(1), dim3(64), 0, stream, k, C, ngroups, gstate);
+    hipLaunchKernelGGL(k_kw_groups<1>, dim3((C * ngroups + 63) / 64), dim3(64), 0, stream, k, C, nchunks, ngroups, states, gstate);
+    hipLaunchKernelGGL(k_kw_apply, dim3((nthreads + 255) / 256), dim3(256), 0, stream, (const float*)da, T, C, st, sc, k, nchunks,
+                       (const double*)states, (double*)c->ws[WS_FILT]);
     hipLaunchKernelGGL(k_block_power, dim3(nblocks, C), dim3(256), 0, stream, (const double*)c->ws[WS_FILT], T,
                        (const int64_t*)c->ws[WS_META], (const int64_t*)((const char*)c->ws[WS_META] + bb), nblocks, 1.0 / norm,
                        (double*)c->ws[WS_SCR2]);

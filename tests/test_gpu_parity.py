@@ -221,3 +221,61 @@ def test_full_size_config2(gpu):
     sub_bank = torch.cat([bank[100:101], bank[100:104]]).contiguous()
     a = ops.convolve_moving_seg(sub_x, sub_bank, sub_seg, path="direct")[:, s0:s1]
     assert_parity(yh[:, s0:s1], a.cpu().numpy())
+
+
+def test_config5_foa_48k(gpu):
+    """BASELINE config 5 (FOA 4-ch, 120 s @ 48 kHz, 500 points, 96000 taps: 768 MB bank, T = 5.76 M):
+    runs at full size; checked by float64 closed-form spot values and the restricted reference oracle."""
+    from sonicsim_amd import ops, synth
+    sc = synth.make_scene("cfg5", scene=1)
+    seg = synth.scene_segments(sc, 1)
+    bank = ops.rir_bank_synth(sc.delay, sc.dgain, sc.L, sc.fs, sc.rt60, sc.bank_seed, device=gpu)
+    ops.peak_normalize_(bank)
+    x = torch.from_numpy(sc.x).to(gpu)
+    y = ops.convolve_moving_seg(x, bank, seg)
+    torch.cuda.synchronize()
+    assert y.shape == (4, 5760000)
+    n3 = int(seg[:3].sum())
+    yh = y[:, :n3].cpu().numpy()
+    bank_h = bank[:4].cpu().numpy()
+    idx, w = moving.expand_segments(seg[:3])
+    ref = moving.convolve_moving_receiver(sc.x[:n3], bank_h, idx, w)
+    assert_parity(yh, ref)
+    k = 317                                                    # a segment deep inside the render
+    s0 = int(seg[:k].sum())
+    pts = np.array([s0, s0 + 1, s0 + int(seg[k]) // 2, s0 + int(seg[k]) - 1])
+    full_idx = np.full(sc.T, k, dtype=np.int64)
+    full_w = np.zeros(sc.T, dtype=np.float32)
+    full_w[s0:s0 + int(seg[k])] = np.linspace(0, 1, int(seg[k]), endpoint=False).astype(np.float32)
+    bk = np.zeros((k + 2, 4, sc.L), dtype=np.float32)
+    bk[k:k + 2] = bank[k:k + 2].cpu().numpy()
+    d = moving.direct_form_f64(sc.x, bk, full_idx, full_w, pts)
+    got = y[:, pts].cpu().numpy()
+    scale = float(np.sqrt(np.mean(y[:, s0:s0 + int(seg[k])].cpu().numpy().astype(np.float64) ** 2)))
+    assert np.abs(d - got).max() < 20 * TOL * scale
+
+
+def test_config3_full_sample_pipeline(gpu):
+    """BASELINE config 3 at reduced size: 3 moving + 2 static renders + LUFS + mix, every stage vs the oracle."""
+    from oracle import loudness as OL
+    from oracle import mix as OM
+    from sonicsim_amd import pipeline
+    cfg = dict(T=80000, P=12, C=4, L=9000, fs=16000, layout="circ")
+    inp = pipeline.make_scene_inputs(gpu, scene=3, config=cfg)
+    mix, stems, gains = pipeline.render_sonicset_sample(inp, sirs=(2.0,), snr=12.0, lufs_seed=99)
+    assert mix.shape == (4, 80000) and len(stems) == 5
+    np.random.seed(99)
+    ref_stems = []
+    for i, (x, bank, seg) in enumerate(inp.speakers):
+        idx, w = moving.expand_segments(seg)
+        ref_stems.append(moving.convolve_moving_receiver(x.cpu().numpy(), bank.cpu().numpy(), idx, w))
+    for (x, h) in inp.statics:
+        ref_stems.append(moving.convolve_fixed_receiver(x.cpu().numpy(), h.cpu().numpy()))
+    ref_norm = []
+    for y, target in zip(ref_stems, pipeline.LUFS_TARGETS):
+        n, g = OL.get_lufs_norm_audio(y.T.astype(np.float32), 16000, target, allow_many_channels=True)
+        ref_norm.append(np.ascontiguousarray(n.T))
+    for a, b in zip(stems, ref_norm):
+        assert_parity(a.cpu().numpy(), b)
+    ref_mix, _ = OM.mix(np.stack(ref_norm[:2]), ref_norm[3][None], np.array([2.0], np.float32), 12.0)
+    assert_parity(mix.cpu().numpy(), ref_mix)

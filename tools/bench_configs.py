@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Secondary timings on the GPU box (not the driver's bench line): BASELINE configs 3 and 5, the static
+render, and per-stage timings of the full SonicSet sample.  Prints one JSON object."""
+import json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+from sonicsim_amd import SonicSim_audio as A, ops, pipeline, synth, mixing
+
+dev = torch.device("cuda:0")
+ops.init(0)
+
+
+def timeit(fn, n=10, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n
+
+
+out = {}
+# config 5: FOA, 120 s @ 48 kHz, P=500, L=96000
+sc = synth.make_scene("cfg5", scene=0)
+seg = synth.scene_segments(sc, 0)
+bank = ops.rir_bank_synth(sc.delay, sc.dgain, sc.L, sc.fs, sc.rt60, sc.bank_seed, device=dev)
+ops.peak_normalize_(bank)
+x = torch.from_numpy(sc.x).to(dev)
+t = timeit(lambda: ops.convolve_moving_seg(x, bank, seg), n=10)
+algb = 4 * sc.P * sc.C * sc.L + 16 * sc.T + 4 * sc.C * sc.T
+out["cfg5"] = {"ms_per_render": t * 1e3, "audio_s_per_s": sc.T / sc.fs / t, "algorithmic_GBps": algb / t / 1e9}
+del bank, x
+# config 2 pieces
+inp = pipeline.make_scene_inputs(dev, scene=0, config="cfg2")
+x0, b0, s0 = inp.speakers[0]
+xs, hs = inp.statics[0]
+out["cfg2_moving_ms"] = timeit(lambda: ops.convolve_moving_seg(x0, b0, s0)) * 1e3
+out["cfg2_static_ms"] = timeit(lambda: ops.convolve_fixed(xs, hs)) * 1e3
+y = ops.convolve_moving_seg(x0, b0, s0)
+np.random.seed(1)
+out["lufs_norm_ms"] = timeit(lambda: A.get_lufs_norm_audio(y, 16000, -17, allow_many_channels=True, channel_first=True), n=5) * 1e3
+spk = torch.stack([y, y * 0.5])
+noi = (y * 0.1)[None]
+out["mix_ms"] = timeit(lambda: mixing.mix_sources(spk, noi, np.array([1.0], np.float32), 12.0), n=5) * 1e3
+tscene = timeit(lambda: pipeline.render_sonicset_sample(inp, lufs_seed=3), n=5, warm=1)
+out["cfg3"] = {"ms_per_scene": tscene * 1e3, "scene_seconds_per_s": 60.0 / tscene}
+print(json.dumps(out))
