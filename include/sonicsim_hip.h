@@ -39,6 +39,8 @@ extern "C" {
 #define SS_FLAG_PATH_DIRECT 0x20u /* force the direct-form engine (exact fp32 fmaf chain)    */
 #define SS_FLAG_GEOM_2048 0x40u   /* overlap-save engine: force B = 2048 / 256-thread workgroups (two parity passes) */
 #define SS_FLAG_GEOM_4096 0x80u   /* overlap-save engine: force B = 4096 / 512-thread persistent workgroups          */
+#define SS_FLAG_GEOM_13 0x200u    /* overlap-save engine: force the software-pipelined B = 4096 geometry (tvfir13.h; default for long filters) */
+#define SS_FLAG_GEOM_ASM 0x400u   /* overlap-save engine: force the hand-scheduled gfx950 assembly kernel (segment / fixed schedules) */
 #define SS_FLAG_LAYOUT_TC 0x100u  /* audio is [T][C] instead of [C][T] (loudness / mix calls) */
 
 int ss_version(void);

@@ -10,7 +10,7 @@ import ctypes
 import os
 
 PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG, "lib", "libsonicsim_hip.so")
+LIB_PATH = os.environ.get("SS_LIB") or os.path.join(PKG, "lib", "libsonicsim_hip.so")   # SS_LIB: A/B builds (tools/)
 
 FLAG_DEVICE_PTR = 0x1
 FLAG_PATH_OS = 0x10
@@ -18,6 +18,8 @@ FLAG_PATH_DIRECT = 0x20
 FLAG_GEOM_2048 = 0x40
 FLAG_GEOM_4096 = 0x80
 FLAG_LAYOUT_TC = 0x100
+FLAG_GEOM_13 = 0x200
+FLAG_GEOM_ASM = 0x400
 
 SS_EINVAL, SS_EHIP, SS_ENOMEM, SS_ENODEV = -1, -2, -3, -4
 

@@ -14,9 +14,12 @@ import sys
 
 PKG = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(PKG, "csrc", "sonicsim_hip.hip")
-DEPS = [SRC, os.path.join(PKG, "csrc", "tvfir_core.h"), os.path.join(PKG, "csrc", "plan.h"),
+DEPS = [SRC, os.path.join(PKG, "csrc", "tvfir_core.h"), os.path.join(PKG, "csrc", "plan.h"), os.path.join(PKG, "csrc", "tvfir13.h"),
         os.path.join(os.path.dirname(PKG), "include", "sonicsim_hip.h")]
 OUT = os.path.join(PKG, "lib", "libsonicsim_hip.so")
+ASM_GEN = os.path.join(os.path.dirname(PKG), "tools", "gen_asm", "os13.py")
+ASM_SRC = os.path.join(PKG, "csrc", "k_os13_gfx950.s")          # generated, committed (reviewable)
+ASM_OUT = os.path.join(PKG, "lib", "k_os13_gfx950.hsaco")
 ARCH = "gfx950"
 
 
@@ -34,17 +37,50 @@ def is_stale() -> bool:
     return any(os.path.getmtime(d) > t for d in DEPS)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    if not force and not is_stale():
+def llvm_bin(name: str) -> str:
+    for root in (os.environ.get("ROCM_PATH"), "/opt/rocm"):
+        if root and os.path.exists(os.path.join(root, "lib", "llvm", "bin", name)):
+            return os.path.join(root, "lib", "llvm", "bin", name)
+    raise RuntimeError(f"{name} not found under /opt/rocm/lib/llvm/bin")
+
+
+def build_asm(force: bool = False, verbose: bool = False) -> str:
+    """Generate, assemble and link the hand-scheduled render kernel (gfx950 code object)."""
+    stale = force or not os.path.exists(ASM_OUT) or os.path.getmtime(ASM_GEN) > os.path.getmtime(ASM_OUT)
+    if not stale:
+        return ASM_OUT
+    os.makedirs(os.path.dirname(ASM_OUT), exist_ok=True)
+    with open(ASM_SRC + ".tmp", "w") as f:
+        subprocess.run([sys.executable, ASM_GEN], check=True, stdout=f)
+    os.replace(ASM_SRC + ".tmp", ASM_SRC)
+    obj = ASM_OUT + ".o"
+    cmds = [[llvm_bin("clang"), "-x", "assembler", "-target", "amdgcn-amd-amdhsa", f"-mcpu={ARCH}", "-c", ASM_SRC, "-o", obj],
+            [llvm_bin("ld.lld"), "-shared", obj, "-o", ASM_OUT + ".tmp"]]
+    for cmd in cmds:
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.run(cmd, check=True)
+    os.replace(ASM_OUT + ".tmp", ASM_OUT)
+    os.remove(obj)
+    return ASM_OUT
+
+
+def build(force: bool = False, verbose: bool = False, extra=None, out=None) -> str:
+    """extra / out: A/B builds with additional hipcc flags into another file (tools/); the product build uses neither."""
+    if out is None and os.environ.get("SS_LIB"):
+        return os.environ["SS_LIB"]
+    if out is None:
+        build_asm(force=force, verbose=verbose)
+    if out is None and not force and not is_stale():
         return OUT
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
     cmd = [hipcc_path(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-shared", "-fPIC",
-           "-Wno-unused-value", "-Wno-unused-result", SRC, "-o", OUT + ".tmp"]
+           "-Wno-unused-value", "-Wno-unused-result", *(extra or []), SRC, "-o", (out or OUT) + ".tmp"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True)
-    os.replace(OUT + ".tmp", OUT)
-    return OUT
+    os.replace((out or OUT) + ".tmp", out or OUT)
+    return out or OUT
 
 
 if __name__ == "__main__":

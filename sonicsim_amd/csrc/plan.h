@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "tvfir_core.h"
+#include "tvfir13.h"
 
 namespace ss {
 
@@ -162,6 +163,23 @@ inline void build_consts12(std::vector<c32>& tab) {
     for (int k = 1; k < 8; ++k)
         for (int n = 0; n < 8; ++n) tab[TW3_12 + (k - 1) * 8 + n] = W((double)((n * k) % 64), 64.0);
     for (int n = 0; n < 4096; ++n) tab[TWIST_12 + n] = W((double)n, 16384.0);   // exp(-i pi n / 8192)
+}
+
+
+// geometry 13: TW1P merges the per-thread part of the right-angle twist into the pass-1 twiddles
+inline void build_consts13(std::vector<c32>& tab) {
+    tab.assign(CONST13_C32, c32{0.f, 0.f});
+    const double PI = 3.14159265358979323846264338327950288;
+    auto W = [&](double num, double den) {
+        const double a = -2.0 * PI * num / den;
+        return c32{(float)std::cos(a), (float)std::sin(a)};
+    };
+    for (int k = 0; k < 8; ++k)
+        for (int t = 0; t < 512; ++t) tab[TW1P_13 + k * 512 + t] = W((double)((t * (1 + 4 * k)) % 16384), 16384.0);   // exp(-i pi t/8192) W_4096^(t k)
+    for (int k = 1; k < 8; ++k)
+        for (int m = 0; m < 64; ++m) tab[TW2_13 + (k - 1) * 64 + m] = W((double)((m * k) % 512), 512.0);
+    for (int k = 1; k < 8; ++k)
+        for (int n = 0; n < 8; ++n) tab[TW3_13 + (k - 1) * 8 + n] = W((double)((n * k) % 64), 64.0);
 }
 
 }  // namespace ss

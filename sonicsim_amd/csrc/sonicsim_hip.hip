@@ -2,6 +2,7 @@
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC (see sonicsim_amd/build.py).
 // Written for CDNA4 only (wave64, 160 KiB LDS, 256 CUs / 8 XCDs); no CUDA compatibility layer.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <cstdarg>
 #include <cstdio>
@@ -32,6 +33,7 @@ struct DevEnv {
         __builtin_amdgcn_wave_barrier();
     }
     __device__ __forceinline__ c32* lds() const { return smem; }
+    __device__ __forceinline__ int uniform(int v) const { return __builtin_amdgcn_readfirstlane(v); }
 };
 
 // input spectra: one workgroup per 2B window
@@ -52,15 +54,24 @@ template <int XD, int ABL = 0> __global__ __launch_bounds__(256, 2) void k_os(Re
 
 // geometry 12 (B = 4096, 512 threads, sliding spectrum window): one workgroup per CU
 __global__ __launch_bounds__(512, 2) void k_xspec12(const float* __restrict__ x, int64_t T, const c32* __restrict__ consts,
-                                                    c32* __restrict__ Xs, int M, float* __restrict__ yzero, int64_t nzero) {
+                                                    c32* __restrict__ Xs, int M, float* __restrict__ yzero, int64_t nzero,
+                                                    int* __restrict__ counter) {
     __shared__ __attribute__((aligned(16))) c32 smem[LDS12_C32];
     DevEnv env{smem};
+    if (counter && blockIdx.x == 0 && threadIdx.x == 0) *counter = 0;     // task-queue head of the render kernel that follows
     xspec12_body(env, x, T, consts, Xs, (int)blockIdx.x, M, yzero, nzero);
 }
 template <int ABL = 0> __global__ __launch_bounds__(512, 2) void k_os12(RenderParams prm) {
     __shared__ __attribute__((aligned(16))) c32 smem[LDS12_C32];
     DevEnv env{smem};
     os12_body<DevEnv, ABL>(env, prm, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// geometry 13 (tvfir13.h): software-pipelined FFT/MAC, one barrier per transform, buffer addressing, dynamic task queue
+__global__ __launch_bounds__(512, 2) void k_os13(Params13 prm) {
+    __shared__ __attribute__((aligned(16))) c32 smem[LDS13_C32];
+    DevEnv env{smem};
+    os13_body(env, prm, (int)blockIdx.x);
 }
 
 // direct-form fallback / cross-check
@@ -398,7 +409,7 @@ int fail(int code, const char* fmt, ...) {
         if (e_ != hipSuccess) return fail(e_ == hipErrorOutOfMemory ? SS_ENOMEM : SS_EHIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
     } while (0)
 
-enum WsSlot { WS_XS, WS_PLAN, WS_BMIN, WS_BMAX, WS_X, WS_BANK, WS_IDX, WS_W, WS_Y, WS_SCR, WS_SCR2, WS_FILT, WS_META, WS_COUNT };
+enum WsSlot { WS_XS, WS_PLAN, WS_BMIN, WS_BMAX, WS_X, WS_BANK, WS_IDX, WS_W, WS_Y, WS_SCR, WS_SCR2, WS_FILT, WS_META, WS_CNT, WS_COUNT };
 
 struct Pinned {
     void* host = nullptr;
@@ -417,6 +428,10 @@ struct Ctx {
     bool inited = false;
     c32* consts = nullptr;
     c32* consts12 = nullptr;
+    c32* consts13 = nullptr;
+    hipModule_t mod13 = nullptr;          // hand-scheduled gfx950 render kernel (tools/gen_asm/os13.py -> lib/k_os13_gfx950.hsaco)
+    hipFunction_t fn13 = nullptr;
+    bool mod13_tried = false;
     int os_geom = 0;        // SS_OS_GEOM: 11 (B=2048, 256 thr) / 12 (B=4096, 512 thr, spectrum window); 0 = by filter length
     void* ws[WS_COUNT] = {};
     size_t ws_cap[WS_COUNT] = {};
@@ -461,6 +476,9 @@ int get_ctx(Ctx** out) {
         build_consts12(tab);
         HIPCHK(hipMalloc((void**)&c->consts12, sizeof(c32) * CONST12_C32));
         HIPCHK(hipMemcpy(c->consts12, tab.data(), sizeof(c32) * CONST12_C32, hipMemcpyHostToDevice));
+        build_consts13(tab);
+        HIPCHK(hipMalloc((void**)&c->consts13, sizeof(c32) * CONST13_C32));
+        HIPCHK(hipMemcpy(c->consts13, tab.data(), sizeof(c32) * CONST13_C32, hipMemcpyHostToDevice));
         hipDeviceProp_t prop;
         HIPCHK(hipGetDeviceProperties(&prop, dev));
         c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -541,6 +559,40 @@ inline int grid_for(int64_t n, int cap = 2048) {
     return (int)g;
 }
 
+// kernel arguments of k_os13_asm (layout fixed by tools/gen_asm/os13.py: ARG)
+struct Os13AsmArgs {
+    const void* bank;
+    const void* Xs;
+    const void* tasks;
+    const void* seg_start;
+    const void* inv_seg;
+    void* y;
+    int64_t T;
+    int32_t P, C, L, NP, M, ntasks, mode, nwg;
+    const void* consts;
+    void* counter;
+};
+static_assert(sizeof(Os13AsmArgs) == 104, "Os13AsmArgs layout");
+
+// The code object sits next to this shared library (built by sonicsim_amd/build.py); a missing file is an error
+// for the callers that asked for the assembly engine, never a silent fallback.
+int load_mod13(Ctx* c) {
+    if (c->fn13) return SS_OK;
+    if (c->mod13_tried) return fail(SS_EHIP, "k_os13_gfx950.hsaco could not be loaded (see the first error)");
+    c->mod13_tried = true;
+    Dl_info info;
+    if (!dladdr((const void*)&ss_version, &info) || !info.dli_fname) return fail(SS_EHIP, "dladdr failed: cannot locate k_os13_gfx950.hsaco");
+    std::string path(info.dli_fname);
+    const size_t slash = path.find_last_of('/');
+    path = (slash == std::string::npos ? std::string(".") : path.substr(0, slash)) + "/k_os13_gfx950.hsaco";
+    if (const char* e = getenv("SS_HSACO")) path = e;
+    hipError_t e = hipModuleLoad(&c->mod13, path.c_str());
+    if (e != hipSuccess) return fail(SS_EHIP, "hipModuleLoad(%s) failed: %s", path.c_str(), hipGetErrorString(e));
+    e = hipModuleGetFunction(&c->fn13, c->mod13, "k_os13_asm");
+    if (e != hipSuccess) return fail(SS_EHIP, "hipModuleGetFunction(k_os13_asm) failed: %s", hipGetErrorString(e));
+    return SS_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // the render engine shared by rows V / I+V / F
 int render(int mode, const float* x, int64_t T, const float* bank, int32_t P, int32_t C, int32_t L,
@@ -593,7 +645,12 @@ int render(int mode, const float* x, int64_t T, const float* bank, int32_t P, in
     int geom = c->os_geom;
     if (flags & SS_FLAG_GEOM_2048) geom = 11;
     if (flags & SS_FLAG_GEOM_4096) geom = 12;
-    const bool g12 = use_os && T < ((int64_t)1 << 30) && (geom == 12 || (geom == 0 && L > 2 * B));
+    if (flags & SS_FLAG_GEOM_13) geom = 13;
+    const bool g13 = use_os && T < ((int64_t)1 << 30) && (int64_t)L * 4 < ((int64_t)1 << 31) && (geom == 13 || (geom == 0 && L > 2 * B));
+    const bool g14 = use_os && T < ((int64_t)1 << 30) && (int64_t)L * 4 < ((int64_t)1 << 31) && mode != COEF_EXPLICIT &&
+                     (geom == 14 || (flags & SS_FLAG_GEOM_ASM));            // hand-scheduled assembly engine (k_os13_asm)
+    const bool g12 = g13 || g14 || (use_os && T < ((int64_t)1 << 30) && geom == 12);     // 13/14 share 12's block size, spectra and plan
+    if (g14 && (rc = load_mod13(c))) return rc;
     const int BB = g12 ? B12 : B;
     const int JM = g12 ? JMAX12 : JMAX;
     const int M = (int)((T + BB - 1) / BB);
@@ -640,11 +697,19 @@ int render(int mode, const float* x, int64_t T, const float* bank, int32_t P, in
         c->plan.tasks[1].clear();
     }
     const size_t n0 = c->plan.tasks[0].size(), n1 = c->plan.tasks[1].size();
-    const size_t seg_bytes = sizeof(int64_t) * (size_t)P;
+    const size_t seg_bytes = 2 * sizeof(int64_t) * (size_t)P;      // [seg_start P x i64][inv_seg P x f64: 1/len(segment k), IEEE double division]
     const size_t blob = seg_bytes + sizeof(Task) * (n0 + n1);
     Pinned* pin;
     if ((rc = pinned_acquire(c, blob, &pin))) return rc;
-    if (mode == COEF_SEG) memcpy(pin->host, c->seg_start.data(), seg_bytes); else memset(pin->host, 0, seg_bytes);
+    memset(pin->host, 0, seg_bytes);
+    if (mode == COEF_SEG) {
+        memcpy(pin->host, c->seg_start.data(), sizeof(int64_t) * (size_t)P);
+        double* inv = reinterpret_cast<double*>((char*)pin->host + sizeof(int64_t) * (size_t)P);
+        for (int k = 0; k + 1 < P; ++k) {
+            const int64_t n = c->seg_start[k + 1] - c->seg_start[k];
+            inv[k] = n > 0 ? 1.0 / (double)n : 0.0;
+        }
+    }
     if (n0) memcpy((char*)pin->host + seg_bytes, c->plan.tasks[0].data(), sizeof(Task) * n0);
     if (n1) memcpy((char*)pin->host + seg_bytes + sizeof(Task) * n0, c->plan.tasks[1].data(), sizeof(Task) * n1);
     if ((rc = ws_ensure(c, WS_PLAN, blob))) return rc;
@@ -664,8 +729,9 @@ int render(int mode, const float* x, int64_t T, const float* bank, int32_t P, in
         prm.Xs = (const c32*)c->ws[WS_XS];
         {
             ProfScope ps(c, stream, 1);
+            if (g13 && (rc = ws_ensure(c, WS_CNT, 64))) return rc;
             if (g12) hipLaunchKernelGGL(k_xspec12, dim3(M + 1), dim3(NT12), 0, stream, dx, T, (const c32*)c->consts12, (c32*)c->ws[WS_XS], M,
-                                        dy, (int64_t)C * T);
+                                        dy, (int64_t)C * T, g13 ? (int*)c->ws[WS_CNT] : (int*)nullptr);
             else hipLaunchKernelGGL(k_xspec, dim3(M + 1), dim3(NT), 0, stream, dx, T, (const c32*)c->consts, (c32*)c->ws[WS_XS], M);
         }
         HIPCHK(hipGetLastError());
@@ -679,7 +745,27 @@ int render(int mode, const float* x, int64_t T, const float* bank, int32_t P, in
         prm.accumulate = g12 ? 2 : parity;
         if (g12 && nt > (size_t)c->num_cu) nt = (size_t)c->num_cu;     // persistent: one workgroup per CU
         ProfScope ps(c, stream, use_os ? 0 : 2);
-        if (!use_os) hipLaunchKernelGGL(k_direct, dim3((unsigned)nt), dim3(NT), 0, stream, prm);
+        if (g14) {
+            Os13AsmArgs a;
+            a.bank = dbank; a.Xs = prm.Xs; a.tasks = prm.tasks;
+            a.seg_start = c->ws[WS_PLAN];
+            a.inv_seg = (const char*)c->ws[WS_PLAN] + sizeof(int64_t) * (size_t)P;
+            a.y = dy; a.T = T; a.P = P; a.C = C; a.L = L; a.NP = NPart; a.M = M;
+            a.ntasks = prm.ntasks; a.mode = mode; a.nwg = (int32_t)nt;
+            a.consts = c->consts13; a.counter = nullptr;
+            size_t asz = sizeof(a);
+            void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &asz, HIP_LAUNCH_PARAM_END};
+            HIPCHK(hipModuleLaunchKernel(c->fn13, (unsigned)nt, 1, 1, NT13, 1, 1, 0, stream, nullptr, cfg));
+        }
+        else if (g13) {
+            Params13 p13;
+            p13.r = prm;
+            p13.r.consts = c->consts13;
+            p13.counter = (int*)c->ws[WS_CNT];
+            p13.nwg = (int32_t)nt;
+            hipLaunchKernelGGL(k_os13, dim3((unsigned)nt), dim3(NT13), 0, stream, p13);
+        }
+        else if (!use_os) hipLaunchKernelGGL(k_direct, dim3((unsigned)nt), dim3(NT), 0, stream, prm);
         else if (g12 && c->os_ablate == 1) hipLaunchKernelGGL(k_os12<1>, dim3((unsigned)nt), dim3(NT12), 0, stream, prm);
         else if (g12 && c->os_ablate == 2) hipLaunchKernelGGL(k_os12<2>, dim3((unsigned)nt), dim3(NT12), 0, stream, prm);
         else if (g12 && c->os_ablate == 4) hipLaunchKernelGGL(k_os12<4>, dim3((unsigned)nt), dim3(NT12), 0, stream, prm);
@@ -751,6 +837,8 @@ int ss_shutdown(void) {
         hipDeviceSynchronize();
         if (c->consts) hipFree(c->consts);
         if (c->consts12) hipFree(c->consts12);
+        if (c->consts13) hipFree(c->consts13);
+        if (c->mod13) hipModuleUnload(c->mod13);
         for (int i = 0; i < WS_COUNT; ++i) if (c->ws[i]) hipFree(c->ws[i]);
         for (auto& p : c->ring) { if (p.host) hipHostFree(p.host); if (p.ev) hipEventDestroy(p.ev); }
         for (auto& e : c->evs) { hipEventDestroy(e.a); hipEventDestroy(e.b); }

@@ -14,7 +14,8 @@ import numpy as np
 from . import _lib
 
 PATHS = {None: 0, "auto": 0, "os": _lib.FLAG_PATH_OS, "direct": _lib.FLAG_PATH_DIRECT,
-         "os2048": _lib.FLAG_PATH_OS | _lib.FLAG_GEOM_2048, "os4096": _lib.FLAG_PATH_OS | _lib.FLAG_GEOM_4096}
+         "os2048": _lib.FLAG_PATH_OS | _lib.FLAG_GEOM_2048, "os4096": _lib.FLAG_PATH_OS | _lib.FLAG_GEOM_4096,
+         "os13": _lib.FLAG_PATH_OS | _lib.FLAG_GEOM_13, "asm": _lib.FLAG_PATH_OS | _lib.FLAG_GEOM_ASM}
 
 
 def _is_torch(a) -> bool:

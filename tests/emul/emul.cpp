@@ -21,10 +21,11 @@ struct HostEnv {
     void barrier() const { bar->arrive_and_wait(); }
     void wave_sync() const { bar->arrive_and_wait(); }   // host threads are not lock-step: use the full barrier
     c32* lds() const { return lds_; }
+    int uniform(int v) const { return v; }
 };
 
 template <class F> static void launch(int grid, F&& body, int nthreads = NT) {
-    std::vector<c32> lds(LDS12_C32);
+    std::vector<c32> lds(LDS13_C32 > LDS12_C32 ? LDS13_C32 : LDS12_C32);
     std::barrier<> bar(nthreads);
     std::vector<std::thread> th;
     th.reserve(nthreads);
@@ -82,7 +83,8 @@ int emul_fft12_roundtrip(const float* zin /*[4096][2]*/, float* slots, float* ba
 // mode: 0 fixed (P==1), 1 seg (seg_len[P-1]), 2 explicit (idx,w).  path: 0 = overlap-save, 1 = direct
 int emul_render(const float* x, int64_t T, const float* bank, int P, int C, int L, int mode,
                 const int64_t* seg_len, const int64_t* idx, const float* w, float* y, int path, int64_t* ntasks, int xd) {
-    const bool g12 = (path == 0 && xd == 12);
+    const bool g13 = (path == 0 && xd == 13);
+    const bool g12 = (path == 0 && xd == 12) || g13;
     const int BB = g12 ? B12 : B;
     std::vector<c32> consts;
     if (g12) build_consts12(consts); else build_consts(consts);
@@ -129,6 +131,18 @@ int emul_render(const float* x, int64_t T, const float* bank, int P, int C, int 
         prm.ntasks = (int)all.size();
         prm.accumulate = 2;
         *ntasks = (int64_t)all.size();
+        if (g13) {
+            std::vector<c32> c13;
+            build_consts13(c13);
+            int counter = 0;
+            Params13 p13;
+            p13.r = prm;
+            p13.r.consts = c13.data();
+            p13.counter = &counter;
+            p13.nwg = std::min<int>(prm.ntasks, 3);
+            launch(p13.nwg, [&](HostEnv& env, int b) { os13_body(env, p13, b); }, NT13);
+            return 0;
+        }
         const int nwg = std::min<int>(prm.ntasks, 5);
         launch(nwg, [&](HostEnv& env, int b) { os12_body(env, prm, b, nwg); }, NT12);
         return 0;

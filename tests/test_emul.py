@@ -19,7 +19,8 @@ ip = ctypes.POINTER(ctypes.c_int64)
 def emul():
     src = os.path.join(HERE, "emul", "emul.cpp")
     out = os.path.join(HERE, "emul", "libss_emul.so")
-    deps = [src, os.path.join(HERE, "..", "sonicsim_amd", "csrc", "tvfir_core.h"), os.path.join(HERE, "..", "sonicsim_amd", "csrc", "plan.h")]
+    deps = [src, os.path.join(HERE, "..", "sonicsim_amd", "csrc", "tvfir_core.h"), os.path.join(HERE, "..", "sonicsim_amd", "csrc", "plan.h"),
+            os.path.join(HERE, "..", "sonicsim_amd", "csrc", "tvfir13.h")]
     if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
         subprocess.run(["g++", "-O2", "-std=c++20", "-shared", "-fPIC", "-pthread", src, "-o", out], check=True)
     return ctypes.CDLL(out)
@@ -78,7 +79,7 @@ def test_fft_slot_mapping(emul):
     assert np.abs((back[:, 0] + 1j * back[:, 1]) / 2048 - z).max() < 5e-6
 
 
-@pytest.mark.parametrize("path,xd", [(0, 3), (0, 12), (1, 0)])
+@pytest.mark.parametrize("path,xd", [(0, 3), (0, 12), (0, 13), (1, 0)])
 def test_kernel_bodies_against_reference_goldens(emul, path, xd):
     """path 0 = overlap-save (xd 3: B=2048 two-pass geometry, xd 12: B=4096 persistent/atomic geometry), 1 = direct."""
     import functools
@@ -111,7 +112,7 @@ def test_zero_length_segments_and_every_sample_written(emul):
     from oracle import moving
     idx, w = moving.expand_segments(seg)
     ref = moving.convolve_moving_receiver(x, bank, idx, w)
-    for xd in (3, 12):
+    for xd in (3, 12, 13):
         y, _ = render(emul, x, bank, 1, seg=seg, path=0, xd=xd)
         assert not np.isnan(y).any()
         assert_parity(y, ref, tol=1e-5)
