@@ -105,7 +105,7 @@ def main():
     torch.cuda.synchronize()
 
     def step():
-        return ops.convolve_moving_seg(x, bank, seg)            # rows I+V: plan on host, 3 kernel launches
+        return ops.convolve_moving_seg(x, bank, seg)            # rows I+V: O(P*C) plan on the host, 2 kernel launches (spectra, render)
 
     y = None
     for _ in range(args.warmup):
@@ -143,7 +143,7 @@ def main():
         if os.path.exists(pmc):
             try:
                 js = json.load(open(pmc))
-                traffic = (js.get("k_os12") or js.get("k_os") or {}).get("hbm_bytes_per_launch")
+                traffic = (js.get("k_os13_asm") or js.get("k_os12") or js.get("k_os") or {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         out = {
@@ -166,7 +166,8 @@ def main():
                        "gather": bool(world > 1 and not args.no_gather)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "k_os12 (row-stationary partitioned overlap-save, B=4096, persistent, one launch per render)",
+                         "kernel": "k_os13_asm (hand-scheduled gfx950 assembly: row-stationary partitioned overlap-save, B=4096, persistent, "
+                                   "one launch per render)",
                          "algorithmic_bytes_per_render": render_bytes, "launches_per_render": launches_per_render,
                          "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_ms": avg_launch_ms,
                          "xspec_avg_launch_ms": ms_xs / max(1, n_xs),

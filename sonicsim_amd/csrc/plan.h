@@ -114,6 +114,56 @@ inline void merge_lpt(Plan& plan, int NP, std::vector<Task>& out) {
     std::stable_sort(out.begin(), out.end(), [&](const Task& a, const Task& b) { return cost(a) > cost(b); });
 }
 
+// Direct O(P*C) planner of the implicit (segment) schedule for the single-launch geometries (12/13/14): row r is responsible
+// for the samples [seg_start[r-1], seg_start[r+1]) (end filter of segment r-1, start filter of segment r -- SonicSim_moving.py
+// :89-94), i.e. for a run of consecutive output blocks, cut into tasks of at most `jmax` blocks.  Tasks come out in descending
+// cost order (the persistent workgroups take them round-robin = LPT), row-major inside a cost class (neighbouring rows share
+// their input-spectra window in L2).  No per-call allocation once `out` / `scratch` have grown.
+inline void plan_seg_lpt(const std::vector<int64_t>& seg_start /*[P], last == T*/, int P, int C, int block, int jmax, int NP,
+                         std::vector<Task>& out, std::vector<int32_t>& scratch) {
+    out.clear();
+    constexpr int MAXCOST = 4096;
+    auto cost = [NP](int j0, int nj) {
+        const int np_eff = std::min(NP, j0 + nj);
+        const int c = np_eff * (10 + 2 * nj) + 12 * nj;
+        return c < MAXCOST ? c : MAXCOST - 1;
+    };
+    scratch.assign(MAXCOST + 1, 0);
+    // pass 1: histogram of costs
+    for (int r = 0; r < P; ++r) {
+        const int64_t a0 = seg_start[r > 0 ? r - 1 : r], a2 = seg_start[r < P - 1 ? r + 1 : r];
+        if (a2 <= a0) continue;
+        int64_t j = a0 / block;
+        const int64_t jhi = (a2 - 1) / block;
+        while (j <= jhi) {
+            const int nj = (int)std::min<int64_t>(jmax, jhi - j + 1);
+            scratch[cost((int)j, nj)] += C;
+            j += nj;
+        }
+    }
+    // descending-cost start offsets
+    int32_t total = 0;
+    for (int c = MAXCOST - 1; c >= 0; --c) { const int32_t n = scratch[c]; scratch[c] = total; total += n; }
+    out.resize((size_t)total);
+    // pass 2: scatter
+    for (int r = 0; r < P; ++r) {
+        const int64_t a0 = seg_start[r > 0 ? r - 1 : r], a2 = seg_start[r < P - 1 ? r + 1 : r];
+        if (a2 <= a0) continue;
+        int64_t j = a0 / block;
+        const int64_t jhi = (a2 - 1) / block;
+        while (j <= jhi) {
+            const int nj = (int)std::min<int64_t>(jmax, jhi - j + 1);
+            int32_t& at = scratch[cost((int)j, nj)];
+            for (int c = 0; c < C; ++c) {
+                Task t;
+                t.row = r; t.chan = c; t.j0 = (int32_t)j; t.nj = nj;
+                out[(size_t)at++] = t;
+            }
+            j += nj;
+        }
+    }
+}
+
 // fixed receiver: one row, every block, store pass only
 inline void build_plan_fixed(int64_t T, int C, int block, int jmax, Plan& plan) {
     plan.tasks[0].clear();
@@ -180,6 +230,25 @@ inline void build_consts13(std::vector<c32>& tab) {
         for (int m = 0; m < 64; ++m) tab[TW2_13 + (k - 1) * 64 + m] = W((double)((m * k) % 512), 512.0);
     for (int k = 1; k < 8; ++k)
         for (int n = 0; n < 8; ++n) tab[TW3_13 + (k - 1) * 8 + n] = W((double)((n * k) % 64), 64.0);
+}
+
+
+// assembly engine (tools/gen_asm/os13.py): row-per-reader tables, row stride 10 c32; image = LDS bytes 0x10000..0x1C000
+constexpr int CONST14_C32 = 12 * 512;
+inline void build_consts14(std::vector<c32>& tab) {
+    tab.assign(CONST14_C32, c32{0.f, 0.f});
+    const double PI = 3.14159265358979323846264338327950288;
+    auto W = [&](double num, double den) {
+        const double a = -2.0 * PI * num / den;
+        return c32{(float)std::cos(a), (float)std::sin(a)};
+    };
+    for (int t = 0; t < 512; ++t)
+        for (int k = 0; k < 8; ++k) tab[t * 10 + k] = W((double)((t * (1 + 4 * k)) % 16384), 16384.0);
+    const int o2 = (0x1A000 - 0x10000) / 8, o3 = (0x1B400 - 0x10000) / 8;
+    for (int m = 0; m < 64; ++m)
+        for (int k = 0; k < 8; ++k) tab[o2 + m * 10 + k] = W((double)((m * k) % 512), 512.0);
+    for (int n = 0; n < 8; ++n)
+        for (int k = 0; k < 8; ++k) tab[o3 + n * 10 + k] = W((double)((n * k) % 64), 64.0);
 }
 
 }  // namespace ss

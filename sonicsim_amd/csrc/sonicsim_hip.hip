@@ -429,6 +429,7 @@ struct Ctx {
     c32* consts = nullptr;
     c32* consts12 = nullptr;
     c32* consts13 = nullptr;
+    c32* consts14 = nullptr;
     hipModule_t mod13 = nullptr;          // hand-scheduled gfx950 render kernel (tools/gen_asm/os13.py -> lib/k_os13_gfx950.hsaco)
     hipFunction_t fn13 = nullptr;
     bool mod13_tried = false;
@@ -441,6 +442,7 @@ struct Ctx {
     bool have_last = false;
     bool prof = false;
     std::vector<EvPair> evs;
+    std::vector<hipEvent_t> ev_pool;      // recycled timing events (creating events costs host time inside the timed loop)
     int os_variant = 3;     // SS_OS_VARIANT: prefetch depth of the render kernel (0, 2, 3) -- tuning knob
     int os_ablate = 0;      // SS_OS_ABLATE: profiling-only ablation mask (results are WRONG when != 0)
     bool xcd_order = true;  // SS_XCD_ORDER=0 disables the XCD-aware task order -- tuning knob
@@ -449,6 +451,7 @@ struct Ctx {
     std::vector<int32_t> bmin, bmax;
     Plan plan;
     std::vector<Task> merged;
+    std::vector<int32_t> plan_scratch;
     int num_cu = 0;
 };
 
@@ -479,6 +482,9 @@ int get_ctx(Ctx** out) {
         build_consts13(tab);
         HIPCHK(hipMalloc((void**)&c->consts13, sizeof(c32) * CONST13_C32));
         HIPCHK(hipMemcpy(c->consts13, tab.data(), sizeof(c32) * CONST13_C32, hipMemcpyHostToDevice));
+        build_consts14(tab);
+        HIPCHK(hipMalloc((void**)&c->consts14, sizeof(c32) * CONST14_C32));
+        HIPCHK(hipMemcpy(c->consts14, tab.data(), sizeof(c32) * CONST14_C32, hipMemcpyHostToDevice));
         hipDeviceProp_t prop;
         HIPCHK(hipGetDeviceProperties(&prop, dev));
         c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -540,7 +546,11 @@ struct ProfScope {
     ProfScope(Ctx* c_, hipStream_t s_, int kind_) : c(c_), s(s_), kind(kind_), on(c_->prof) {
         if (on) {
             ev.kind = kind;
-            if (hipEventCreate(&ev.a) != hipSuccess || hipEventCreate(&ev.b) != hipSuccess) { on = false; return; }
+            auto get = [&](hipEvent_t* e) {
+                if (!c->ev_pool.empty()) { *e = c->ev_pool.back(); c->ev_pool.pop_back(); return true; }
+                return hipEventCreate(e) == hipSuccess;
+            };
+            if (!get(&ev.a) || !get(&ev.b)) { on = false; return; }
             hipEventRecord(ev.a, s);
         }
     }
@@ -646,9 +656,11 @@ int render(int mode, const float* x, int64_t T, const float* bank, int32_t P, in
     if (flags & SS_FLAG_GEOM_2048) geom = 11;
     if (flags & SS_FLAG_GEOM_4096) geom = 12;
     if (flags & SS_FLAG_GEOM_13) geom = 13;
-    const bool g13 = use_os && T < ((int64_t)1 << 30) && (int64_t)L * 4 < ((int64_t)1 << 31) && (geom == 13 || (geom == 0 && L > 2 * B));
+    if (geom == 0 && mode == COEF_EXPLICIT && L > 2 * B) geom = 12;      // explicit (idx, w) schedules: HIP geometry 12
+    const bool g13 = use_os && T < ((int64_t)1 << 30) && (int64_t)L * 4 < ((int64_t)1 << 31) && geom == 13;
     const bool g14 = use_os && T < ((int64_t)1 << 30) && (int64_t)L * 4 < ((int64_t)1 << 31) && mode != COEF_EXPLICIT &&
-                     (geom == 14 || (flags & SS_FLAG_GEOM_ASM));            // hand-scheduled assembly engine (k_os13_asm)
+                     (geom == 14 || (flags & SS_FLAG_GEOM_ASM) || (geom == 0 && L > 2 * B));   // hand-scheduled assembly engine (k_os13_asm):
+                                                                                                // the default for long filters
     const bool g12 = g13 || g14 || (use_os && T < ((int64_t)1 << 30) && geom == 12);     // 13/14 share 12's block size, spectra and plan
     if (g14 && (rc = load_mod13(c))) return rc;
     const int BB = g12 ? B12 : B;
@@ -668,7 +680,6 @@ int render(int mode, const float* x, int64_t T, const float* bank, int32_t P, in
         }
         c->seg_start[P - 1] = s;
         if (s != T) return fail(SS_EINVAL, "sum(seg_len) = %lld != T = %lld", (long long)s, (long long)T);
-        seg_minmax(c->seg_start, T, c->bmin, c->bmax);
     } else if (mode == COEF_EXPLICIT) {
         if ((rc = ws_ensure(c, WS_BMIN, sizeof(int32_t) * nfine))) return rc;
         if ((rc = ws_ensure(c, WS_BMAX, sizeof(int32_t) * nfine))) return rc;
@@ -685,13 +696,20 @@ int render(int mode, const float* x, int64_t T, const float* bank, int32_t P, in
                 return fail(SS_EINVAL, "interp_index out of range [0, %d] near sample %lld (min %d, max %d)", P - 2,
                             (long long)(b * DTILE), c->bmin[b], c->bmax[b]);
     }
-    if (mode == COEF_FIXED) build_plan_fixed(T, C, use_os ? BB : DTILE, use_os ? JM : 1, c->plan);
-    else build_plan(c->bmin, c->bmax, P, C, use_os ? BB / DTILE : 1, use_os ? JM : 1, c->plan);
-    if (c->xcd_order) { xcd_interleave(c->plan.tasks[0]); xcd_interleave(c->plan.tasks[1]); }
+    const bool fast_plan = g12 && mode == COEF_SEG;        // single-launch geometries, implicit schedule: O(P*C) direct planner
+    if (fast_plan) {
+        plan_seg_lpt(c->seg_start, P, C, BB, JM, NPart, c->plan.tasks[0], c->plan_scratch);
+        c->plan.tasks[1].clear();
+    } else {
+        if (mode == COEF_SEG) seg_minmax(c->seg_start, T, c->bmin, c->bmax);
+        if (mode == COEF_FIXED) build_plan_fixed(T, C, use_os ? BB : DTILE, use_os ? JM : 1, c->plan);
+        else build_plan(c->bmin, c->bmax, P, C, use_os ? BB / DTILE : 1, use_os ? JM : 1, c->plan);
+        if (c->xcd_order) { xcd_interleave(c->plan.tasks[0]); xcd_interleave(c->plan.tasks[1]); }
+    }
 
     // ---- upload plan blob: [seg_start (P int64)][tasks parity 0][tasks parity 1]
     //      geometry 12: ONE list in LPT order (atomic accumulation, persistent workgroups)
-    if (g12) {
+    if (g12 && !fast_plan) {
         merge_lpt(c->plan, NPart, c->merged);
         c->plan.tasks[0].swap(c->merged);
         c->plan.tasks[1].clear();
@@ -752,10 +770,22 @@ int render(int mode, const float* x, int64_t T, const float* bank, int32_t P, in
             a.inv_seg = (const char*)c->ws[WS_PLAN] + sizeof(int64_t) * (size_t)P;
             a.y = dy; a.T = T; a.P = P; a.C = C; a.L = L; a.NP = NPart; a.M = M;
             a.ntasks = prm.ntasks; a.mode = mode; a.nwg = (int32_t)nt;
-            a.consts = c->consts13; a.counter = nullptr;
+            a.consts = c->consts14; a.counter = nullptr;
+            const char* trace_file = getenv("SS_TRACE_FILE");      // timeline trace of a code object built with OS13_OPT=trace (tools/)
+            if (trace_file) {
+                if ((rc = ws_ensure(c, WS_CNT, 512 * 1024))) return rc;
+                HIPCHK(hipMemsetAsync(c->ws[WS_CNT], 0, 512 * 1024, stream));
+                a.counter = c->ws[WS_CNT];
+            }
             size_t asz = sizeof(a);
             void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &asz, HIP_LAUNCH_PARAM_END};
             HIPCHK(hipModuleLaunchKernel(c->fn13, (unsigned)nt, 1, 1, NT13, 1, 1, 0, stream, nullptr, cfg));
+            if (trace_file) {
+                std::vector<char> hb(512 * 1024);
+                HIPCHK(hipMemcpyAsync(hb.data(), c->ws[WS_CNT], hb.size(), hipMemcpyDeviceToHost, stream));
+                HIPCHK(hipStreamSynchronize(stream));
+                if (FILE* f = fopen(trace_file, "wb")) { fwrite(hb.data(), 1, hb.size(), f); fclose(f); }
+            }
         }
         else if (g13) {
             Params13 p13;
@@ -838,10 +868,12 @@ int ss_shutdown(void) {
         if (c->consts) hipFree(c->consts);
         if (c->consts12) hipFree(c->consts12);
         if (c->consts13) hipFree(c->consts13);
+        if (c->consts14) hipFree(c->consts14);
         if (c->mod13) hipModuleUnload(c->mod13);
         for (int i = 0; i < WS_COUNT; ++i) if (c->ws[i]) hipFree(c->ws[i]);
         for (auto& p : c->ring) { if (p.host) hipHostFree(p.host); if (p.ev) hipEventDestroy(p.ev); }
         for (auto& e : c->evs) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
+        for (auto& e : c->ev_pool) hipEventDestroy(e);
         delete c;
     }
     g_ctx.clear();
@@ -1159,8 +1191,10 @@ int ss_prof_enable(int on) {
     int rc = get_ctx(&c);
     if (rc) return rc;
     HIPCHK(hipDeviceSynchronize());
-    for (auto& e : c->evs) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
+    for (auto& e : c->evs) { c->ev_pool.push_back(e.a); c->ev_pool.push_back(e.b); }
     c->evs.clear();
+    if (on && c->ev_pool.size() < 256)
+        for (int i = 0; i < 256; ++i) { hipEvent_t e; if (hipEventCreate(&e) == hipSuccess) c->ev_pool.push_back(e); }
     c->prof = on != 0;
     return SS_OK;
 }

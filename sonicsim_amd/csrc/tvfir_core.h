@@ -702,10 +702,16 @@ template <class Env> SS_HD void load_consts12(Env& env, const Lds12& l, const c3
 template <class Env> SS_HD void xspec12_body(Env& env, const float* x, int64_t T, const c32* consts, c32* Xs, int m, int M,
                                              float* yzero = nullptr, int64_t nzero = 0) {
     const int tid = env.tid();
-    if (yzero) {   // zero this workgroup's slice of y for the atomic accumulation of the render kernel
-        const int64_t chunk = (nzero + M) / (M + 1);
-        const int64_t lo = (int64_t)m * chunk, hi = lo + chunk < nzero ? lo + chunk : nzero;
-        for (int64_t i = lo + tid; i < hi; i += NT12) yzero[i] = 0.0f;
+    if (yzero) {   // zero this workgroup's slice of y for the atomic accumulation of the render kernel (16-byte stores)
+        const bool al = (reinterpret_cast<uintptr_t>(yzero) & 15) == 0;
+        const int64_t n4 = al ? nzero / 4 : 0;
+        const int64_t chunk = (n4 + M) / (M + 1);
+        const int64_t lo = (int64_t)m * chunk, hi = lo + chunk < n4 ? lo + chunk : n4;
+        f4* y4 = reinterpret_cast<f4*>(yzero);
+        const f4 z{0.0f, 0.0f, 0.0f, 0.0f};
+        for (int64_t i = lo + tid; i < hi; i += NT12) y4[i] = z;
+        if (m == 0)
+            for (int64_t i = n4 * 4 + tid; i < nzero; i += NT12) yzero[i] = 0.0f;
     }
     if (m >= M) {
         c32* z = Xs + (int64_t)M * B12;

@@ -80,6 +80,54 @@ int emul_fft12_roundtrip(const float* zin /*[4096][2]*/, float* slots, float* ba
     return 0;
 }
 
+// planner cross-check: the direct O(P*C) segment planner must emit exactly the tasks of the generic (min/max driven) planner
+// whose row actually owns samples; returns 0 when consistent, otherwise a positive diagnostic code
+int emul_plan_compare(const int64_t* seg_len, int P, int C, int L, int64_t* nfast, int64_t* ngeneric) {
+    std::vector<int64_t> seg_start(P);
+    int64_t s = 0;
+    for (int k = 0; k < P - 1; ++k) { seg_start[k] = s; s += seg_len[k]; }
+    seg_start[P - 1] = s;
+    const int64_t T = s;
+    const int NP = (L + B12 - 1) / B12;
+    std::vector<Task> fast;
+    std::vector<int32_t> scratch;
+    plan_seg_lpt(seg_start, P, C, B12, JMAX12, NP, fast, scratch);
+    std::vector<int32_t> bmin, bmax;
+    seg_minmax(seg_start, T, bmin, bmax);
+    Plan plan;
+    build_plan(bmin, bmax, P, C, B12 / DTILE, JMAX12, plan);
+    std::vector<Task> gen;
+    merge_lpt(plan, NP, gen);
+    *nfast = (int64_t)fast.size();
+    *ngeneric = (int64_t)gen.size();
+    auto key = [](const Task& t) { return ((int64_t)t.row << 40) | ((int64_t)t.chan << 32) | (uint32_t)t.j0; };
+    // every sample of every (row, channel) must be covered exactly once by the fast plan
+    std::vector<int64_t> covered((size_t)P * C, 0);
+    for (const Task& t : fast) {
+        if (t.nj < 1 || t.nj > JMAX12) return 1;
+        const int64_t a0 = seg_start[t.row > 0 ? t.row - 1 : t.row], a2 = seg_start[t.row < P - 1 ? t.row + 1 : t.row];
+        const int64_t lo = std::max<int64_t>(a0, (int64_t)t.j0 * B12), hi = std::min<int64_t>(a2, (int64_t)(t.j0 + t.nj) * B12);
+        if (hi <= lo) return 2;                                       // a task that owns no sample
+        covered[(size_t)t.row * C + t.chan] += hi - lo;
+    }
+    for (int r = 0; r < P; ++r) {
+        const int64_t a0 = seg_start[r > 0 ? r - 1 : r], a2 = seg_start[r < P - 1 ? r + 1 : r];
+        for (int c = 0; c < C; ++c)
+            if (covered[(size_t)r * C + c] != std::max<int64_t>(0, a2 - a0)) return 3;
+    }
+    // descending cost order
+    auto cost = [NP](const Task& t) { const int np_eff = std::min(NP, t.j0 + t.nj); return np_eff * (10 + 2 * t.nj) + 12 * t.nj; };
+    for (size_t i = 1; i < fast.size(); ++i)
+        if (cost(fast[i]) > cost(fast[i - 1])) return 4;
+    // the generic plan covers a superset of (row, chan, block) pairs
+    std::vector<int64_t> gk;
+    for (const Task& t : gen) for (int j = 0; j < t.nj; ++j) { Task u = t; u.j0 = t.j0 + j; gk.push_back(key(u)); }
+    std::sort(gk.begin(), gk.end());
+    for (const Task& t : fast)
+        for (int j = 0; j < t.nj; ++j) { Task u = t; u.j0 = t.j0 + j; if (!std::binary_search(gk.begin(), gk.end(), key(u))) return 5; }
+    return 0;
+}
+
 // mode: 0 fixed (P==1), 1 seg (seg_len[P-1]), 2 explicit (idx,w).  path: 0 = overlap-save, 1 = direct
 int emul_render(const float* x, int64_t T, const float* bank, int P, int C, int L, int mode,
                 const int64_t* seg_len, const int64_t* idx, const float* w, float* y, int path, int64_t* ntasks, int xd) {

@@ -116,3 +116,24 @@ def test_zero_length_segments_and_every_sample_written(emul):
         y, _ = render(emul, x, bank, 1, seg=seg, path=0, xd=xd)
         assert not np.isnan(y).any()
         assert_parity(y, ref, tol=1e-5)
+
+
+def test_direct_segment_planner_matches_generic_planner(emul):
+    """plan_seg_lpt (the O(P*C) host planner of the single-launch geometries) against the min/max-driven planner."""
+    rng = np.random.default_rng(21)
+    cases = [np.array([3000, 0, 0, 2500, 1500]), np.array([0, 0, 7000, 0, 0]), np.array([1, 1, 1, 1, 6996]), np.array([4096] * 9),
+             np.array([4095, 4097, 1, 8191, 12288])]
+    for _ in range(20):
+        Pn = int(rng.integers(2, 60))
+        seg = rng.integers(0, 20000, Pn - 1)
+        seg[rng.random(Pn - 1) < 0.2] = 0
+        if seg.sum() == 0:
+            seg[0] = 5
+        cases.append(seg)
+    for seg in cases:
+        seg = np.ascontiguousarray(seg, np.int64)
+        nf, ng = ctypes.c_int64(0), ctypes.c_int64(0)
+        for L in (300, 6000, 48000):
+            rc = emul.emul_plan_compare(P(seg, ip), len(seg) + 1, 3, L, ctypes.byref(nf), ctypes.byref(ng))
+            assert rc == 0, (rc, seg.tolist(), L)
+            assert 0 < nf.value <= ng.value

@@ -1,0 +1,97 @@
+"""GPU parity of the hand-scheduled gfx950 assembly engine (k_os13_asm, the default for long filters) and of the HIP
+geometry-13 kernel: golden vectors of the reference, the pinned oracle on seeded shapes (ragged T / L, every block-count
+class nj = 1..4, zero-length segments, P = 2), fixed-receiver renders, and properties at BASELINE config-2 size.
+Gate: RMS(y - y_ref)/RMS(y_ref) <= 1e-4 per channel and overall (fp32)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import moving
+from util import assert_parity, golden, golden_inputs, rel_rms
+
+pytestmark = pytest.mark.gpu
+PATHS = ["asm", "os13"]
+
+
+def _seg(idx, P):
+    return np.bincount(idx, minlength=P - 1).astype(np.int64)
+
+
+@pytest.mark.parametrize("path", PATHS)
+def test_reference_goldens(gpu, path):
+    from sonicsim_amd import ops
+    g = golden("g1_fixed_cfg1.npz")                      # BASELINE config 1
+    assert_parity(ops.convolve_fixed(g["x"], g["h"], path=path), g["y"])
+    g = golden("g2_fixed_torch.npz")
+    assert_parity(ops.convolve_fixed(g["x"], g["h"], path=path), g["y"])
+    g = golden("g4_moving_small.npz")
+    assert_parity(ops.convolve_moving_seg(g["x"], g["bank"], _seg(g["idx"], 5), path=path), g["y"])
+    g = golden("g5_moving_medium.npz")
+    x, bank, pos = golden_inputs(int(g["seed"]), int(g["T"]), int(g["P"]), int(g["C"]), int(g["L"]))
+    xd, bd = torch.from_numpy(x).to(gpu), torch.from_numpy(bank).to(gpu)
+    assert_parity(ops.convolve_moving_seg(xd, bd, g["seg_len"], path=path).cpu().numpy(), g["y"])
+
+
+@pytest.mark.parametrize("path", PATHS)
+@pytest.mark.parametrize("T,P,C,L,seed", [(30000, 4, 2, 7000, 11), (50000, 30, 4, 2049, 12), (20480, 3, 1, 4096, 13), (9999, 7, 3, 300, 14),
+                                          (4097, 2, 2, 100, 15), (140000, 9, 2, 20000, 16), (65536, 2, 1, 8193, 17), (100001, 40, 3, 12289, 18)])
+def test_oracle_seeded_shapes(gpu, path, T, P, C, L, seed):
+    from sonicsim_amd import ops
+    x, bank, pos = golden_inputs(seed, T, P, C, L)
+    np.random.seed(seed)
+    idx, w = moving.setup_dynamic_interp(pos, T)
+    ref = moving.convolve_moving_receiver(x, bank, idx, w)
+    assert_parity(ops.convolve_moving_seg(x, bank, _seg(idx, P), path=path), ref)
+    assert_parity(ops.convolve_fixed(x, bank[0], path=path), moving.convolve_fixed_receiver(x, bank[0]))
+
+
+@pytest.mark.parametrize("path", PATHS)
+def test_zero_length_segments_and_block_count_classes(gpu, path):
+    from sonicsim_amd import ops
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal(70000).astype(np.float32)
+    bank = (rng.standard_normal((6, 2, 9000)) * np.exp(-4 * np.arange(9000) / 9000)).astype(np.float32)
+    for seg in ([30000, 0, 0, 25000, 15000], [0, 0, 70000, 0, 0], [1, 1, 1, 1, 69996], [69999, 0, 0, 0, 1], [4096, 4096, 8192, 20480, 33136],
+                [100, 200, 300, 400, 69000]):
+        seg = np.array(seg)
+        idx, w = moving.expand_segments(seg)
+        ref = moving.convolve_moving_receiver(x, bank, idx, w)
+        assert_parity(ops.convolve_moving_seg(x, bank, seg, path=path), ref)
+
+
+def test_asm_is_the_default_engine_for_long_filters(gpu):
+    from sonicsim_amd import ops
+    x, bank, pos = golden_inputs(31, 90000, 12, 2, 9000)
+    np.random.seed(31)
+    seg = moving.segment_lengths(pos, 90000)
+    xd, bd = torch.from_numpy(x).to(gpu), torch.from_numpy(bank).to(gpu)
+    assert torch.equal(ops.convolve_moving_seg(xd, bd, seg), ops.convolve_moving_seg(xd, bd, seg, path="asm"))
+    assert torch.equal(ops.convolve_fixed(xd, bd[0]), ops.convolve_fixed(xd, bd[0], path="asm"))
+
+
+def test_full_size_config2_asm(gpu):
+    """BASELINE config 2 (T=960000, P=200, C=8, L=48000) on the assembly engine: agreement with the HIP geometries (different
+    schedules and accumulation orders), exact power-of-two linearity, determinism, restricted reference oracle."""
+    from sonicsim_amd import ops, synth
+    sc = synth.make_scene("cfg2", scene=0)
+    seg = synth.scene_segments(sc, 0)
+    bank = ops.rir_bank_synth(sc.delay, sc.dgain, sc.L, sc.fs, sc.rt60, sc.bank_seed, device=gpu)
+    ops.peak_normalize_(bank)
+    x = torch.from_numpy(sc.x).to(gpu)
+    y = ops.convolve_moving_seg(x, bank, seg, path="asm")
+    torch.cuda.synchronize()
+    yh = y.cpu().numpy()
+    assert np.isfinite(yh).all() and yh.shape == (8, 960000)
+    assert rel_rms(yh, ops.convolve_moving_seg(x, bank, seg, path="os4096").cpu().numpy()) < 2e-6
+    assert rel_rms(yh, ops.convolve_moving_seg(x, bank, seg, path="os2048").cpu().numpy()) < 2e-6
+    assert torch.equal(ops.convolve_moving_seg(2 * x, bank, seg, path="asm"), 2 * y)
+    assert torch.equal(ops.convolve_moving_seg(x, bank, seg, path="asm"), y)              # two float atomics per sample onto zero: order free
+    n5 = int(seg[:5].sum())
+    idx, w = moving.expand_segments(seg)
+    ref = moving.convolve_moving_receiver(sc.x[:n5], bank[:6].cpu().numpy(), idx[:n5], w[:n5])
+    assert_parity(yh[:, :n5], ref)
+    # static render at config-2 shapes (noise / music stems of config 3)
+    ys = ops.convolve_fixed(x, bank[17], path="asm")
+    assert rel_rms(ys.cpu().numpy(), ops.convolve_fixed(x, bank[17], path="os4096").cpu().numpy()) < 2e-6
+    nref = 60000
+    assert_parity(ys[:, :nref].cpu().numpy(), moving.convolve_fixed_receiver(sc.x[:nref], bank[17].cpu().numpy()))

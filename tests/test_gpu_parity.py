@@ -47,7 +47,8 @@ def test_golden_medium_device_pointers(gpu):
         assert_parity(ops.convolve_moving_seg(xd, bd, g["seg_len"], path=path).cpu().numpy(), g["y"])
     idx, w = moving.expand_segments(g["seg_len"])
     y2 = ops.convolve_moving(xd, bd, torch.from_numpy(idx).to(gpu), torch.from_numpy(w).to(gpu))
-    assert torch.equal(y, y2)
+    assert torch.equal(ops.convolve_moving_seg(xd, bd, g["seg_len"], path="os4096"), y2)   # same engine: implicit ramp == explicit (idx, w), bit for bit
+    assert rel_rms(y.cpu().numpy(), y2.cpu().numpy()) < 2e-6                              # default engine for this L = assembly kernel
     yd = ops.convolve_moving_seg(xd, bd, g["seg_len"], path="direct")
     assert_parity(yd.cpu().numpy(), g["y"])
 
@@ -173,7 +174,7 @@ def test_linearity_and_channel_permutation(gpu):
     assert rel_rms(yab, 2 * ya - 3 * yb) < 1e-5
     perm = np.array([2, 0, 3, 1])
     assert np.array_equal(ops.convolve_moving_seg(x1, bank[:, perm], seg), ya[perm])
-    yd = ops.convolve_moving_seg(x1, bank, seg)                     # deterministic: no atomics anywhere
+    yd = ops.convolve_moving_seg(x1, bank, seg)                     # deterministic: at most two float atomics per sample onto zero
     assert np.array_equal(yd, ya)
 
 
@@ -209,7 +210,7 @@ def test_full_size_config2(gpu):
     # (b2) the two transform geometries (different FFT sizes, block grids and accumulation schemes) agree
     y11 = ops.convolve_moving_seg(x, bank, seg, path="os2048").cpu().numpy()
     y12 = ops.convolve_moving_seg(x, bank, seg, path="os4096").cpu().numpy()
-    assert rel_rms(y11, y12) < 2e-6 and np.array_equal(y12, yh)
+    assert rel_rms(y11, y12) < 2e-6 and rel_rms(y12, yh) < 2e-6      # default engine = assembly kernel (tests/test_gpu_asm.py)
     # (c) linearity at full size: render(2x) == 2 render(x) bit-exactly (power-of-two scaling)
     y2 = ops.convolve_moving_seg(2 * x, bank, seg)
     assert torch.equal(y2, 2 * y)
