@@ -445,6 +445,7 @@ struct Ctx {
     std::vector<hipEvent_t> ev_pool;      // recycled timing events (creating events costs host time inside the timed loop)
     int os_variant = 3;     // SS_OS_VARIANT: prefetch depth of the render kernel (0, 2, 3) -- tuning knob
     int os_ablate = 0;      // SS_OS_ABLATE: profiling-only ablation mask (results are WRONG when != 0)
+    bool zero_copy = true;  // SS_ZERO_COPY_PLAN=0: upload the plan with a stream-ordered copy instead of device-mapped pinned memory
     bool xcd_order = true;  // SS_XCD_ORDER=0 disables the XCD-aware task order -- tuning knob
     // host scratch reused across calls
     std::vector<int64_t> seg_start;
@@ -492,6 +493,7 @@ int get_ctx(Ctx** out) {
         if (const char* e = getenv("SS_OS_VARIANT")) c->os_variant = atoi(e);
         if (const char* e = getenv("SS_OS_ABLATE")) c->os_ablate = atoi(e);
         if (const char* e = getenv("SS_XCD_ORDER")) c->xcd_order = atoi(e) != 0;
+        if (const char* e = getenv("SS_ZERO_COPY_PLAN")) c->zero_copy = atoi(e) != 0;
         c->inited = true;
     }
     *out = c;
@@ -730,16 +732,26 @@ int render(int mode, const float* x, int64_t T, const float* bank, int32_t P, in
     }
     if (n0) memcpy((char*)pin->host + seg_bytes, c->plan.tasks[0].data(), sizeof(Task) * n0);
     if (n1) memcpy((char*)pin->host + seg_bytes + sizeof(Task) * n0, c->plan.tasks[1].data(), sizeof(Task) * n1);
-    if ((rc = ws_ensure(c, WS_PLAN, blob))) return rc;
-    HIPCHK(hipMemcpyAsync(c->ws[WS_PLAN], pin->host, blob, hipMemcpyHostToDevice, stream));
-    HIPCHK(hipEventRecord(pin->ev, stream));
-    pin->pending = true;
+    // The assembly engine reads its plan (28 KB of task descriptors fetched a task ahead by scalar loads + the segment table)
+    // straight from the pinned, device-mapped host buffer: no in-stream DMA copy ahead of the kernels (its start-up latency
+    // would sit on the critical path of every render).  Other geometries take the copy.
+    const bool zero_copy_plan = g14 && c->zero_copy;
+    const char* plan_base;
+    if (zero_copy_plan) {
+        plan_base = (const char*)pin->host;
+    } else {
+        if ((rc = ws_ensure(c, WS_PLAN, blob))) return rc;
+        HIPCHK(hipMemcpyAsync(c->ws[WS_PLAN], pin->host, blob, hipMemcpyHostToDevice, stream));
+        HIPCHK(hipEventRecord(pin->ev, stream));
+        pin->pending = true;
+        plan_base = (const char*)c->ws[WS_PLAN];
+    }
 
     RenderParams prm;
     memset(&prm, 0, sizeof(prm));
     prm.x = dx; prm.T = T; prm.bank = dbank; prm.P = P; prm.C = C; prm.L = L; prm.NP = NPart;
     prm.M = M; prm.consts = g12 ? c->consts12 : c->consts; prm.mode = mode;
-    prm.seg_start = (const int64_t*)c->ws[WS_PLAN];
+    prm.seg_start = (const int64_t*)plan_base;
     prm.idx = didx; prm.w = dw; prm.y = dy;
 
     if (use_os) {
@@ -754,7 +766,7 @@ int render(int mode, const float* x, int64_t T, const float* bank, int32_t P, in
         }
         HIPCHK(hipGetLastError());
     }
-    const Task* dtasks = (const Task*)((const char*)c->ws[WS_PLAN] + seg_bytes);
+    const Task* dtasks = (const Task*)(plan_base + seg_bytes);
     for (int parity = 0; parity < 2; ++parity) {
         size_t nt = parity ? n1 : n0;
         if (!nt) continue;
@@ -766,8 +778,8 @@ int render(int mode, const float* x, int64_t T, const float* bank, int32_t P, in
         if (g14) {
             Os13AsmArgs a;
             a.bank = dbank; a.Xs = prm.Xs; a.tasks = prm.tasks;
-            a.seg_start = c->ws[WS_PLAN];
-            a.inv_seg = (const char*)c->ws[WS_PLAN] + sizeof(int64_t) * (size_t)P;
+            a.seg_start = plan_base;
+            a.inv_seg = plan_base + sizeof(int64_t) * (size_t)P;
             a.y = dy; a.T = T; a.P = P; a.C = C; a.L = L; a.NP = NPart; a.M = M;
             a.ntasks = prm.ntasks; a.mode = mode; a.nwg = (int32_t)nt;
             a.consts = c->consts14; a.counter = nullptr;
@@ -780,6 +792,10 @@ int render(int mode, const float* x, int64_t T, const float* bank, int32_t P, in
             size_t asz = sizeof(a);
             void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &asz, HIP_LAUNCH_PARAM_END};
             HIPCHK(hipModuleLaunchKernel(c->fn13, (unsigned)nt, 1, 1, NT13, 1, 1, 0, stream, nullptr, cfg));
+            if (zero_copy_plan) {          // the ring slot may be rewritten only after this kernel has consumed it
+                HIPCHK(hipEventRecord(pin->ev, stream));
+                pin->pending = true;
+            }
             if (trace_file) {
                 std::vector<char> hb(512 * 1024);
                 HIPCHK(hipMemcpyAsync(hb.data(), c->ws[WS_CNT], hb.size(), hipMemcpyDeviceToHost, stream));
