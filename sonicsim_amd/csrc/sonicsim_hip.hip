@@ -67,6 +67,16 @@ template <int ABL = 0> __global__ __launch_bounds__(512, 2) void k_os12(RenderPa
     os12_body<DevEnv, ABL>(env, prm, (int)blockIdx.x, (int)gridDim.x);
 }
 
+// input spectra for the assembly / geometry-13 render kernels (no zero spectrum: their descriptors return zeros out of range)
+__global__ __launch_bounds__(512, 2) void k_xspec13(const float* __restrict__ x, int64_t T, const c32* __restrict__ consts,
+                                                    c32* __restrict__ Xs, int M, float* __restrict__ yzero, int64_t nzero,
+                                                    int* __restrict__ counter) {
+    __shared__ __attribute__((aligned(16))) c32 smem[LDS13_C32];
+    DevEnv env{smem};
+    if (counter && blockIdx.x == 0 && threadIdx.x == 0) *counter = 0;
+    xspec13_body(env, x, T, consts, Xs, (int)blockIdx.x, M, yzero, nzero);
+}
+
 // geometry 13 (tvfir13.h): software-pipelined FFT/MAC, one barrier per transform, buffer addressing, dynamic task queue
 __global__ __launch_bounds__(512, 2) void k_os13(Params13 prm) {
     __shared__ __attribute__((aligned(16))) c32 smem[LDS13_C32];
@@ -760,8 +770,10 @@ int render(int mode, const float* x, int64_t T, const float* bank, int32_t P, in
         {
             ProfScope ps(c, stream, 1);
             if (g13 && (rc = ws_ensure(c, WS_CNT, 64))) return rc;
-            if (g12) hipLaunchKernelGGL(k_xspec12, dim3(M + 1), dim3(NT12), 0, stream, dx, T, (const c32*)c->consts12, (c32*)c->ws[WS_XS], M,
-                                        dy, (int64_t)C * T, g13 ? (int*)c->ws[WS_CNT] : (int*)nullptr);
+            if (g13 || g14) hipLaunchKernelGGL(k_xspec13, dim3(M + 1), dim3(NT13), 0, stream, dx, T, (const c32*)c->consts13, (c32*)c->ws[WS_XS], M,
+                                               dy, (int64_t)C * T, g13 ? (int*)c->ws[WS_CNT] : (int*)nullptr);
+            else if (g12) hipLaunchKernelGGL(k_xspec12, dim3(M + 1), dim3(NT12), 0, stream, dx, T, (const c32*)c->consts12, (c32*)c->ws[WS_XS], M,
+                                        dy, (int64_t)C * T, (int*)nullptr);
             else hipLaunchKernelGGL(k_xspec, dim3(M + 1), dim3(NT), 0, stream, dx, T, (const c32*)c->consts, (c32*)c->ws[WS_XS], M);
         }
         HIPCHK(hipGetLastError());

@@ -332,6 +332,74 @@ SS_HD void g13_step(Env& env, const Lds13& l, const P& prm, const Task13& tk, St
     g13_mac(s.acc[0], s.W[(0 - PH) & 3], v);
 }
 
+// Input spectra on the geometry-13 tables (36 KB of constants instead of 64 KB, the x window is requested before the
+// constants are staged, 16-byte zero fill): window m = x[(m-1)B, (m+1)B) folded to z[n] = (lo - i hi) * exp(-i pi n / 8192),
+// spectrum in the slot layout the render kernels read (c32 index ((r>>1)*512 + tid)*2 + (r&1)).
+template <class Env> SS_HD void xspec13_body(Env& env, const float* x, int64_t T, const c32* consts, c32* Xs, int m, int M,
+                                             float* yzero, int64_t nzero) {
+    const int tid = env.tid();
+    float lo[8], hi[8];
+    if (m < M) {
+#pragma unroll
+        for (int n1 = 0; n1 < 8; ++n1) {
+            const int n = n1 * 512 + tid;
+            const int64_t tlo = (int64_t)(m - 1) * B13 + n, thi = (int64_t)m * B13 + n;
+            lo[n1] = (tlo >= 0 && tlo < T) ? x[tlo] : 0.0f;
+            hi[n1] = (thi < T) ? x[thi] : 0.0f;
+        }
+    }
+    if (yzero) {   // this workgroup's slice of y (the render kernel accumulates with float atomics onto zero)
+        const bool al = (reinterpret_cast<uintptr_t>(yzero) & 15) == 0;
+        const int64_t n4 = al ? nzero / 4 : 0;
+        const int64_t chunk = (n4 + M) / (M + 1);
+        const int64_t zlo = (int64_t)m * chunk, zhi = zlo + chunk < n4 ? zlo + chunk : n4;
+        f4* y4 = reinterpret_cast<f4*>(yzero);
+        const f4 z{0.0f, 0.0f, 0.0f, 0.0f};
+        for (int64_t i = zlo + tid; i < zhi; i += NT13) y4[i] = z;
+        if (m == 0)
+            for (int64_t i = n4 * 4 + tid; i < nzero; i += NT13) yzero[i] = 0.0f;
+    }
+    if (m >= M) return;              // (there is no zero spectrum any more: the render kernels' descriptors return zeros)
+    Lds13 l; l.base = env.lds();
+    load_consts13(env, l, consts);
+    const int wave = tid >> 6, lane = tid & 63;
+    c32* Pv = l.priv(wave);
+    c32 v[8];
+#pragma unroll
+    for (int n1 = 0; n1 < 8; ++n1)
+        v[n1] = mk(lo[n1] * SS_C16(n1) - hi[n1] * SS_S16(n1), -(lo[n1] * SS_S16(n1)) - hi[n1] * SS_C16(n1));
+    dft8f<false>(v);
+    c32* C = l.cross(0);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) C[k * 512 + tid] = cmul(v[k], l.tw1p()[k * 512 + tid]);
+    env.barrier();
+#pragma unroll
+    for (int n = 0; n < 8; ++n) v[n] = C[wave * 512 + n * 64 + lane];
+    dft8f<false>(v);
+    Pv[lane] = v[0];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) Pv[k * 72 + lane] = cmul(v[k], l.tw2()[(k - 1) * 64 + lane]);
+    env.wave_sync();
+    const int k2 = lane >> 3, n4 = lane & 7;
+#pragma unroll
+    for (int n = 0; n < 8; ++n) v[n] = Pv[k2 * 72 + n * 8 + n4];
+    dft8f<false>(v);
+    env.wave_sync();
+    Pv[(k2 * 8) * 9 + n4] = v[0];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) Pv[(k2 * 8 + k) * 9 + n4] = cmul(v[k], l.tw3()[(k - 1) * 8 + n4]);
+    env.wave_sync();
+#pragma unroll
+    for (int n = 0; n < 8; ++n) v[n] = Pv[lane * 9 + n];
+    dft8f<false>(v);
+    c32* out = Xs + (int64_t)m * B13;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        out[(q * 512 + tid) * 2 + 0] = v[2 * q];
+        out[(q * 512 + tid) * 2 + 1] = v[2 * q + 1];
+    }
+}
+
 // inverse transform (slot order in, v[n1] = conj(tau[tid]) * z[n1*512 + tid] * B out); `par` picks the cross buffer
 template <class Env> SS_HD void g13_inv(Env& env, const Lds13& l, c32* v, int par) {
     const int tid = env.tid();

@@ -139,7 +139,11 @@ int emul_render(const float* x, int64_t T, const float* bank, int P, int C, int 
     const int M = (int)((T + BB - 1) / BB);
     std::vector<c32> Xs((size_t)(M + 1) * BB);
     if (path == 0 && !g12) launch(M + 1, [&](HostEnv& env, int m) { xspec_body(env, x, T, consts.data(), Xs.data(), m, M); });
-    if (g12) launch(M + 1, [&](HostEnv& env, int m) { xspec12_body(env, x, T, consts.data(), Xs.data(), m, M, y, (int64_t)C * T); }, NT12);
+    if (g13) {
+        std::vector<c32> c13;
+        build_consts13(c13);
+        launch(M + 1, [&](HostEnv& env, int m) { xspec13_body(env, x, T, c13.data(), Xs.data(), m, M, y, (int64_t)C * T); }, NT13);
+    } else if (g12) launch(M + 1, [&](HostEnv& env, int m) { xspec12_body(env, x, T, consts.data(), Xs.data(), m, M, y, (int64_t)C * T); }, NT12);
 
     Plan plan;
     std::vector<int64_t> seg_start;

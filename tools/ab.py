@@ -15,6 +15,6 @@ for spec in sys.argv[1:]:
         if not line:
             print(spec, "FAILED", out.stderr[-500:]); break
         j = json.loads(line[-1])
-        vals.append((j["ms_per_step"], j["roofline"]["avg_launch_ms"], j["roofline"]["frac"], j["value"]))
+        vals.append((j["ms_per_step"], j["roofline"]["avg_launch_ms"], j["roofline"]["frac"], j["value"], j["roofline"]["xspec_avg_launch_ms"]))
     for v in vals:
-        print(f"{spec:45s} ms/step {v[0]:.4f}  k_os avg launch {v[1]*1e3:8.1f} us  frac {v[2]:.4f}  value {v[3]:.0f}")
+        print(f"{spec:45s} ms/step {v[0]:.4f}  k_os avg launch {v[1]*1e3:8.1f} us  frac {v[2]:.4f}  value {v[3]:.0f}  xspec {v[4]*1e3:.1f} us")
