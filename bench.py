@@ -111,7 +111,7 @@ def main():
     for _ in range(args.warmup):
         y = step()
     torch.cuda.synchronize()
-    ops.prof_enable(True)
+    ops.prof_enable(not os.environ.get("BENCH_NOPROF"))        # BENCH_NOPROF=1: measure the event-free step time (diagnostics)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()

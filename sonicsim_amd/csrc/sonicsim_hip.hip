@@ -593,8 +593,10 @@ struct Os13AsmArgs {
     int32_t P, C, L, NP, M, ntasks, mode, nwg;
     const void* consts;
     void* counter;
+    const void* idx;       // explicit schedule (mode 2): interp_index int64[T], interp_weight float[T]
+    const void* w;
 };
-static_assert(sizeof(Os13AsmArgs) == 104, "Os13AsmArgs layout");
+static_assert(sizeof(Os13AsmArgs) == 120, "Os13AsmArgs layout");
 
 // The code object sits next to this shared library (built by sonicsim_amd/build.py); a missing file is an error
 // for the callers that asked for the assembly engine, never a silent fallback.
@@ -668,9 +670,8 @@ int render(int mode, const float* x, int64_t T, const float* bank, int32_t P, in
     if (flags & SS_FLAG_GEOM_2048) geom = 11;
     if (flags & SS_FLAG_GEOM_4096) geom = 12;
     if (flags & SS_FLAG_GEOM_13) geom = 13;
-    if (geom == 0 && mode == COEF_EXPLICIT && L > 2 * B) geom = 12;      // explicit (idx, w) schedules: HIP geometry 12
     const bool g13 = use_os && T < ((int64_t)1 << 30) && (int64_t)L * 4 < ((int64_t)1 << 31) && geom == 13;
-    const bool g14 = use_os && T < ((int64_t)1 << 30) && (int64_t)L * 4 < ((int64_t)1 << 31) && mode != COEF_EXPLICIT &&
+    const bool g14 = use_os && T < ((int64_t)1 << 30) && (int64_t)L * 4 < ((int64_t)1 << 31) &&
                      (geom == 14 || (flags & SS_FLAG_GEOM_ASM) || (geom == 0 && L > 2 * B));   // hand-scheduled assembly engine (k_os13_asm):
                                                                                                 // the default for long filters
     const bool g12 = g13 || g14 || (use_os && T < ((int64_t)1 << 30) && geom == 12);     // 13/14 share 12's block size, spectra and plan
@@ -795,6 +796,7 @@ int render(int mode, const float* x, int64_t T, const float* bank, int32_t P, in
             a.y = dy; a.T = T; a.P = P; a.C = C; a.L = L; a.NP = NPart; a.M = M;
             a.ntasks = prm.ntasks; a.mode = mode; a.nwg = (int32_t)nt;
             a.consts = c->consts14; a.counter = nullptr;
+            a.idx = didx; a.w = dw;
             const char* trace_file = getenv("SS_TRACE_FILE");      // timeline trace of a code object built with OS13_OPT=trace (tools/)
             if (trace_file) {
                 if ((rc = ws_ensure(c, WS_CNT, 512 * 1024))) return rc;

@@ -41,8 +41,11 @@ def test_oracle_seeded_shapes(gpu, path, T, P, C, L, seed):
     np.random.seed(seed)
     idx, w = moving.setup_dynamic_interp(pos, T)
     ref = moving.convolve_moving_receiver(x, bank, idx, w)
-    assert_parity(ops.convolve_moving_seg(x, bank, _seg(idx, P), path=path), ref)
+    y = ops.convolve_moving_seg(x, bank, _seg(idx, P), path=path)
+    assert_parity(y, ref)
     assert_parity(ops.convolve_fixed(x, bank[0], path=path), moving.convolve_fixed_receiver(x, bank[0]))
+    if path == "asm":      # explicit (idx, w) schedule on the same engine: the implicit ramp is bit-identical
+        assert np.array_equal(ops.convolve_moving(x, bank, idx, w, path=path), y)
 
 
 @pytest.mark.parametrize("path", PATHS)
@@ -57,6 +60,22 @@ def test_zero_length_segments_and_block_count_classes(gpu, path):
         idx, w = moving.expand_segments(seg)
         ref = moving.convolve_moving_receiver(x, bank, idx, w)
         assert_parity(ops.convolve_moving_seg(x, bank, seg, path=path), ref)
+
+
+def test_explicit_schedule_arbitrary_index(gpu):
+    """convolve_moving_receiver's contract allows ANY per-sample idx in [0, P-2] and any w (SonicSim_moving.py:89-94 is a gather)."""
+    from sonicsim_amd import ops
+    g = golden("g8_arbitrary_idx.npz")
+    assert_parity(ops.convolve_moving(g["x"], g["bank"], g["idx"], g["w"], path="asm"), g["y"])
+    rng = np.random.default_rng(3)
+    T, P, C, L = 60000, 7, 2, 9000
+    x = rng.standard_normal(T).astype(np.float32)
+    bank = (rng.standard_normal((P, C, L)) * np.exp(-4 * np.arange(L) / L)).astype(np.float32)
+    idx = np.repeat(rng.integers(0, P - 1, T // 500 + 1), 500)[:T].astype(np.int64)         # piecewise-constant, non-monotone
+    w = rng.random(T).astype(np.float32)
+    ref = moving.convolve_moving_receiver(x, bank, idx, w)
+    assert_parity(ops.convolve_moving(x, bank, idx, w, path="asm"), ref)
+    assert_parity(ops.convolve_moving(x, bank, idx, w), ref)                                # default engine
 
 
 def test_asm_is_the_default_engine_for_long_filters(gpu):

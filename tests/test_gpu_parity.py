@@ -47,8 +47,9 @@ def test_golden_medium_device_pointers(gpu):
         assert_parity(ops.convolve_moving_seg(xd, bd, g["seg_len"], path=path).cpu().numpy(), g["y"])
     idx, w = moving.expand_segments(g["seg_len"])
     y2 = ops.convolve_moving(xd, bd, torch.from_numpy(idx).to(gpu), torch.from_numpy(w).to(gpu))
-    assert torch.equal(ops.convolve_moving_seg(xd, bd, g["seg_len"], path="os4096"), y2)   # same engine: implicit ramp == explicit (idx, w), bit for bit
-    assert rel_rms(y.cpu().numpy(), y2.cpu().numpy()) < 2e-6                              # default engine for this L = assembly kernel
+    assert torch.equal(y, y2)                                 # same (default = assembly) engine: implicit ramp == explicit (idx, w), bit for bit
+    y12 = ops.convolve_moving(xd, bd, torch.from_numpy(idx).to(gpu), torch.from_numpy(w).to(gpu), path="os4096")
+    assert torch.equal(ops.convolve_moving_seg(xd, bd, g["seg_len"], path="os4096"), y12)   # ... and on HIP geometry 12
     yd = ops.convolve_moving_seg(xd, bd, g["seg_len"], path="direct")
     assert_parity(yd.cpu().numpy(), g["y"])
 
