@@ -21,7 +21,7 @@ KNOWN_BANK_BYTES = 4 * 200 * 8 * 48000      # bench config 2
 
 
 def short(name):
-    for k in ("k_os13_asm", "k_os13", "k_os12", "k_xspec12", "k_os", "k_xspec", "k_direct", "k_absmax", "k_divide", "k_rir_synth", "k_idx_minmax"):
+    for k in ("k_os13_asm", "k_os13", "k_os12", "k_xspec13", "k_xspec12", "k_os", "k_xspec", "k_direct", "k_absmax", "k_divide", "k_rir_synth", "k_idx_minmax"):
         if k in name:
             return k
     return name.split("(")[0][:60]
@@ -73,7 +73,7 @@ def main():
     res["calibration"] = {"fetch_factor_dword_stream": fcal, "write_factor_dword_stream": wcal,
                           "known_bytes": KNOWN_BANK_BYTES}
     print(f"== calibration on known byte counts: fetch x{fcal}  write x{wcal}")
-    for k in ("k_os13_asm", "k_os13", "k_os12", "k_os", "k_xspec12", "k_xspec"):
+    for k in ("k_os13_asm", "k_os13", "k_os12", "k_os", "k_xspec13", "k_xspec12", "k_xspec"):
         if k in allc and "FETCH_SIZE" in allc[k]:
             f_raw = allc[k]["FETCH_SIZE"] * 1024.0
             w_raw = allc[k].get("WRITE_SIZE", 0.0) * 1024.0
