@@ -110,6 +110,10 @@ def main():
     y = None
     for _ in range(args.warmup):
         y = step()
+    if world > 1 and not args.no_gather:
+        if y is None:
+            y = step()
+        parallel.gather_to_root(y, dst=0)          # untimed: RCCL builds its point-to-point channels on first use
     torch.cuda.synchronize()
     ops.prof_enable(not os.environ.get("BENCH_NOPROF"))        # BENCH_NOPROF=1: measure the event-free step time (diagnostics)
     if world > 1:
