@@ -210,11 +210,32 @@ __global__ __launch_bounds__(256) void k_partial_sum(const float* __restrict__ x
     __syncthreads();
     if (threadIdx.x == 0) partial[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = (sw[0] + sw[1]) + (sw[2] + sw[3]);
 }
-__global__ void k_final_sum(const double* __restrict__ partial, int nb, double* __restrict__ out) {
+// fixed-order final sum: lane l adds partial[l], partial[l + 64], ... then a butterfly over the 64 lanes (deterministic)
+__global__ __launch_bounds__(64) void k_final_sum(const double* __restrict__ partial, int nb, double* __restrict__ out) {
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nb; i += 64) s += partial[(int64_t)blockIdx.x * nb + i];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (threadIdx.x == 0) out[blockIdx.x] = s;
+}
+// out = gain * in with the float64 partial sums of out and in in the same pass (pyloudnorm.normalize.loudness + :78-79)
+__global__ __launch_bounds__(256) void k_scale_sums(const float* __restrict__ in, float* __restrict__ out, int64_t n, float gain,
+                                                    double* __restrict__ partial /*[2][grid]*/) {
+    __shared__ double sw[2][4];
+    double so = 0.0, si = 0.0;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        const float v = in[i];
+        const float o = gain * v;
+        out[i] = o;
+        so += (double)o;
+        si += (double)v;
+    }
+    for (int o = 32; o > 0; o >>= 1) { so += __shfl_xor(so, o); si += __shfl_xor(si, o); }
+    if ((threadIdx.x & 63) == 0) { sw[0][threadIdx.x >> 6] = so; sw[1][threadIdx.x >> 6] = si; }
+    __syncthreads();
     if (threadIdx.x == 0) {
-        double s = 0.0;
-        for (int i = 0; i < nb; ++i) s += partial[(int64_t)blockIdx.x * nb + i];
-        out[blockIdx.x] = s;
+        partial[blockIdx.x] = (sw[0][0] + sw[0][1]) + (sw[0][2] + sw[0][3]);
+        partial[gridDim.x + blockIdx.x] = (sw[1][0] + sw[1][1]) + (sw[1][2] + sw[1][3]);
     }
 }
 
@@ -292,10 +313,9 @@ __global__ __launch_bounds__(256) void k_scale(const float* __restrict__ in, flo
 struct KwCoef {
     double b[2][3], a[2][3];
     double Mx[16];   // state transition over one full chunk (row-major 4x4)
-    double Mg[16];   // state transition over one full group of KW_GROUP chunks
+    double Mg[16];   // state transition over one scan group (gsz chunks, chosen per call)
 };
 constexpr int KW_CHUNK = 128;    // samples per thread in the sample-level passes
-constexpr int KW_GROUP = 128;    // chunks per thread in the chunk-level scan
 
 __device__ __forceinline__ double kw_step(const KwCoef& k, double s[4], double xin) {
     const double y1 = k.b[0][0] * xin + s[0];
@@ -326,45 +346,50 @@ __global__ __launch_bounds__(256) void k_kw_state(const float* __restrict__ audi
     double* o = states + ((int64_t)c * nchunks + ch) * 4;
     o[0] = s[0]; o[1] = s[1]; o[2] = s[2]; o[3] = s[3];
 }
-// pass 2 (MODE 0): per group of KW_GROUP chunks, from a zero group state: end state of the group.
-// pass 4 (MODE 1): same walk from the TRUE group start state: states[] := start state of every chunk.
-template <int MODE>
-__global__ __launch_bounds__(64) void k_kw_groups(KwCoef k, int C, int nchunks, int ngroups, double* __restrict__ states,
-                                                  double* __restrict__ gstate /*[C][ngroups][4]*/) {
-    const int id = blockIdx.x * 64 + threadIdx.x;
-    if (id >= C * ngroups) return;
-    const int c = id / ngroups, g = id - c * ngroups;
+// passes 2-4 in ONE launch: workgroup = channel, thread = group of gsz chunks.  (a) end state of every group from a zero
+// group state, (b) thread 0 propagates the group states serially (few dozen groups), (c) every thread re-walks its group from
+// the true start state and rewrites states[] := start state of every chunk.
+__global__ __launch_bounds__(256) void k_kw_scan(KwCoef k, int nchunks, int ngroups, int gsz, double* __restrict__ states) {
+    __shared__ double gs[256][4];
+    const int c = blockIdx.x, g = threadIdx.x;
+    double* st = states + (int64_t)c * nchunks * 4;
+    const int c0 = g * gsz, c1 = c0 + gsz < nchunks ? c0 + gsz : nchunks;
     double s[4] = {0, 0, 0, 0};
-    double* gs = gstate + ((int64_t)c * ngroups + g) * 4;
-    if (MODE == 1) { s[0] = gs[0]; s[1] = gs[1]; s[2] = gs[2]; s[3] = gs[3]; }
-    const int c0 = g * KW_GROUP, c1 = c0 + KW_GROUP < nchunks ? c0 + KW_GROUP : nchunks;
-    for (int ch = c0; ch < c1; ++ch) {
-        double* z = states + ((int64_t)c * nchunks + ch) * 4;
-        const double z0 = z[0], z1 = z[1], z2 = z[2], z3 = z[3];
-        if (MODE == 1) { z[0] = s[0]; z[1] = s[1]; z[2] = s[2]; z[3] = s[3]; }
-        double nx[4];
-        kw_matvec(k.Mx, s, nx);
-        s[0] = nx[0] + z0; s[1] = nx[1] + z1; s[2] = nx[2] + z2; s[3] = nx[3] + z3;
+    if (g < ngroups) {
+        for (int ch = c0; ch < c1; ++ch) {
+            double nx[4];
+            kw_matvec(k.Mx, s, nx);
+            s[0] = nx[0] + st[ch * 4 + 0]; s[1] = nx[1] + st[ch * 4 + 1]; s[2] = nx[2] + st[ch * 4 + 2]; s[3] = nx[3] + st[ch * 4 + 3];
+        }
+        gs[g][0] = s[0]; gs[g][1] = s[1]; gs[g][2] = s[2]; gs[g][3] = s[3];
     }
-    if (MODE == 0) { gs[0] = s[0]; gs[1] = s[1]; gs[2] = s[2]; gs[3] = s[3]; }
-}
-// pass 3: serial over the (few) groups of each channel: gstate[] := start state of every group
-__global__ void k_kw_scan_groups(KwCoef k, int C, int ngroups, double* __restrict__ gstate) {
-    const int c = threadIdx.x;
-    if (c >= C) return;
-    double s[4] = {0, 0, 0, 0};
-    for (int g = 0; g < ngroups; ++g) {
-        double* z = gstate + ((int64_t)c * ngroups + g) * 4;
-        const double z0 = z[0], z1 = z[1], z2 = z[2], z3 = z[3];
-        z[0] = s[0]; z[1] = s[1]; z[2] = s[2]; z[3] = s[3];
-        double nx[4];
-        kw_matvec(k.Mg, s, nx);
-        s[0] = nx[0] + z0; s[1] = nx[1] + z1; s[2] = nx[2] + z2; s[3] = nx[3] + z3;
+    __syncthreads();
+    if (g == 0) {
+        double a[4] = {0, 0, 0, 0};
+        for (int q = 0; q < ngroups; ++q) {
+            const double z0 = gs[q][0], z1 = gs[q][1], z2 = gs[q][2], z3 = gs[q][3];
+            gs[q][0] = a[0]; gs[q][1] = a[1]; gs[q][2] = a[2]; gs[q][3] = a[3];
+            double nx[4];
+            kw_matvec(k.Mg, a, nx);
+            a[0] = nx[0] + z0; a[1] = nx[1] + z1; a[2] = nx[2] + z2; a[3] = nx[3] + z3;
+        }
+    }
+    __syncthreads();
+    if (g < ngroups) {
+        s[0] = gs[g][0]; s[1] = gs[g][1]; s[2] = gs[g][2]; s[3] = gs[g][3];
+        for (int ch = c0; ch < c1; ++ch) {
+            const double z0 = st[ch * 4 + 0], z1 = st[ch * 4 + 1], z2 = st[ch * 4 + 2], z3 = st[ch * 4 + 3];
+            st[ch * 4 + 0] = s[0]; st[ch * 4 + 1] = s[1]; st[ch * 4 + 2] = s[2]; st[ch * 4 + 3] = s[3];
+            double nx[4];
+            kw_matvec(k.Mx, s, nx);
+            s[0] = nx[0] + z0; s[1] = nx[1] + z1; s[2] = nx[2] + z2; s[3] = nx[3] + z3;
+        }
     }
 }
-// pass 5: re-run every chunk from its true start state, write the K-weighted signal (float64, [C][T])
-__global__ __launch_bounds__(256) void k_kw_apply(const float* __restrict__ audio, int64_t T, int C, int64_t st, int64_t sc, KwCoef k,
-                                                  int nchunks, const double* __restrict__ states, double* __restrict__ filt /*[C][T]*/) {
+// pass 5': re-run every chunk from its true start state and keep only the chunk's K-weighted energy (float64): the gating
+// blocks are sums of whole chunks plus two partial edge chunks (k_block_power_chunks), so the filtered signal is never stored
+__global__ __launch_bounds__(256) void k_kw_energy(const float* __restrict__ audio, int64_t T, int C, int64_t st, int64_t sc, KwCoef k,
+                                                   int nchunks, const double* __restrict__ states, double* __restrict__ energy /*[C][nchunks]*/) {
     const int id = blockIdx.x * 256 + threadIdx.x;
     if (id >= C * nchunks) return;
     const int c = id / nchunks, ch = id - c * nchunks;
@@ -373,27 +398,55 @@ __global__ __launch_bounds__(256) void k_kw_apply(const float* __restrict__ audi
     const int64_t t0 = (int64_t)ch * KW_CHUNK;
     const int64_t t1 = t0 + KW_CHUNK < T ? t0 + KW_CHUNK : T;
     const float* a = audio + c * sc;
-    double* f = filt + (int64_t)c * T;
+    double e = 0.0;
 #pragma unroll 8
-    for (int64_t t = t0; t < t1; ++t) f[t] = kw_step(k, s, (double)a[t * st]);
+    for (int64_t t = t0; t < t1; ++t) {
+        const double v = kw_step(k, s, (double)a[t * st]);
+        e += v * v;
+    }
+    energy[(int64_t)c * nchunks + ch] = e;
 }
-__global__ __launch_bounds__(256) void k_block_power(const double* __restrict__ filt, int64_t T, const int64_t* __restrict__ lo,
-                                                     const int64_t* __restrict__ hi, int nblocks, double inv_norm,
-                                                     double* __restrict__ z /*[C][nblocks]*/) {
-    __shared__ double sw[4];
+// z[c][j] = (1/norm) * sum_{t in [lo_j, hi_j)} k(x_c)[t]^2 from the chunk energies: whole chunks are added in a fixed order by
+// the 64 lanes, the (at most two) partial edge chunks are re-filtered from their stored start state by lanes 0 and 1.
+__global__ __launch_bounds__(64) void k_block_power_chunks(const float* __restrict__ audio, int64_t T, int64_t st, int64_t sc, KwCoef k,
+                                                           int nchunks, const double* __restrict__ states, const double* __restrict__ energy,
+                                                           const int64_t* __restrict__ lo, const int64_t* __restrict__ hi, int nblocks,
+                                                           double inv_norm, double* __restrict__ z /*[C][nblocks]*/) {
     const int j = blockIdx.x, c = blockIdx.y;
     int64_t a = lo[j], b = hi[j];
     a = a < 0 ? 0 : a;
     b = b > T ? T : b;
     double s = 0.0;
-    for (int64_t t = a + threadIdx.x; t < b; t += 256) {
-        const double v = filt[(int64_t)c * T + t];
-        s += v * v;
+    if (b > a) {
+        const int64_t ca = a / KW_CHUNK, cb = (b - 1) / KW_CHUNK;                 // first / last chunk touched
+        const int64_t cb_end = (cb + 1) * KW_CHUNK < T ? (cb + 1) * KW_CHUNK : T;
+        const bool head_whole = a == ca * KW_CHUNK, tail_whole = b == cb_end;
+        const double* e = energy + (int64_t)c * nchunks;
+        int64_t edge = -1;                                                        // chunk this lane re-filters (lanes 0 / 1 only)
+        if (ca == cb) {
+            if (head_whole && tail_whole) { if (threadIdx.x == 0) s += e[ca]; }
+            else if (threadIdx.x == 0) edge = ca;
+        } else {
+            const int64_t f0 = head_whole ? ca : ca + 1, f1 = tail_whole ? cb + 1 : cb;
+            for (int64_t q = f0 + threadIdx.x; q < f1; q += 64) s += e[q];
+            if (threadIdx.x == 0 && !head_whole) edge = ca;
+            if (threadIdx.x == 1 && !tail_whole) edge = cb;
+        }
+        if (edge >= 0) {
+            const double* zz = states + ((int64_t)c * nchunks + edge) * 4;
+            double sv[4] = {zz[0], zz[1], zz[2], zz[3]};
+            const int64_t t0 = edge * KW_CHUNK;
+            int64_t t1 = t0 + KW_CHUNK < T ? t0 + KW_CHUNK : T;
+            t1 = t1 < b ? t1 : b;
+            const float* au = audio + c * sc;
+            for (int64_t t = t0; t < t1; ++t) {
+                const double v = kw_step(k, sv, (double)au[t * st]);
+                if (t >= a) s += v * v;
+            }
+        }
     }
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-    if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) z[(int64_t)c * nblocks + j] = inv_norm * ((sw[0] + sw[1]) + (sw[2] + sw[3]));
+    if (threadIdx.x == 0) z[(int64_t)c * nblocks + j] = inv_norm * s;
 }
 
 // =============================================================================================
@@ -419,7 +472,7 @@ int fail(int code, const char* fmt, ...) {
         if (e_ != hipSuccess) return fail(e_ == hipErrorOutOfMemory ? SS_ENOMEM : SS_EHIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
     } while (0)
 
-enum WsSlot { WS_XS, WS_PLAN, WS_BMIN, WS_BMAX, WS_X, WS_BANK, WS_IDX, WS_W, WS_Y, WS_SCR, WS_SCR2, WS_FILT, WS_META, WS_CNT, WS_COUNT };
+enum WsSlot { WS_XS, WS_PLAN, WS_BMIN, WS_BMAX, WS_X, WS_BANK, WS_IDX, WS_W, WS_Y, WS_SCR, WS_SCR2, WS_FILT, WS_META, WS_CNT, WS_LUFS, WS_COUNT };
 
 struct Pinned {
     void* host = nullptr;
@@ -463,6 +516,8 @@ struct Ctx {
     Plan plan;
     std::vector<Task> merged;
     std::vector<int32_t> plan_scratch;
+    std::vector<int64_t> lufs_bounds;     // block bounds currently resident in ws[WS_LUFS]
+    void* lufs_bounds_dev = nullptr;
     int num_cu = 0;
 };
 
@@ -1132,46 +1187,58 @@ int ss_kweighted_block_power_f32(const float* audio, int64_t T, int32_t C, const
         }
         for (int r = 0; r < 4; ++r) k.Mx[r * 4 + u] = s[r];
     }
-    {   // Mg = Mx ^ KW_GROUP by repeated multiplication (KW_GROUP is a power of two: 7 squarings)
-        double A[16], Bm[16];
+    const int nchunks = (int)((T + KW_CHUNK - 1) / KW_CHUNK);
+    int gsz = (nchunks + 255) / 256;                     // chunks per scan thread: one workgroup of <= 256 threads per channel
+    if (gsz < 16) gsz = 16;
+    const int ngroups = (nchunks + gsz - 1) / gsz;
+    {   // Mg = Mx ^ gsz (square and multiply)
+        double R[16], A[16], Bm[16];
+        for (int i = 0; i < 16; ++i) R[i] = (i % 5 == 0) ? 1.0 : 0.0;
         memcpy(A, k.Mx, sizeof(A));
-        for (int g = KW_GROUP; g > 1; g >>= 1) {
+        auto mul = [&](const double* X, const double* Y, double* Z) {
             for (int r = 0; r < 4; ++r)
                 for (int q = 0; q < 4; ++q) {
                     double acc = 0;
-                    for (int m = 0; m < 4; ++m) acc += A[r * 4 + m] * A[m * 4 + q];
-                    Bm[r * 4 + q] = acc;
+                    for (int m = 0; m < 4; ++m) acc += X[r * 4 + m] * Y[m * 4 + q];
+                    Z[r * 4 + q] = acc;
                 }
+        };
+        for (int e = gsz; e > 0; e >>= 1) {
+            if (e & 1) { mul(A, R, Bm); memcpy(R, Bm, sizeof(R)); }
+            mul(A, A, Bm);
             memcpy(A, Bm, sizeof(A));
         }
-        memcpy(k.Mg, A, sizeof(A));
+        memcpy(k.Mg, R, sizeof(R));
     }
-    const int nchunks = (int)((T + KW_CHUNK - 1) / KW_CHUNK);
-    const int ngroups = (nchunks + KW_GROUP - 1) / KW_GROUP;
-    if ((rc = ws_ensure(c, WS_SCR, sizeof(double) * 4 * ((size_t)C * nchunks + (size_t)C * ngroups)))) return rc;
-    if ((rc = ws_ensure(c, WS_FILT, sizeof(double) * (size_t)C * T))) return rc;
+    if ((rc = ws_ensure(c, WS_SCR, sizeof(double) * 4 * (size_t)C * nchunks))) return rc;
+    if ((rc = ws_ensure(c, WS_FILT, sizeof(double) * (size_t)C * nchunks))) return rc;          // chunk energies
     const size_t bb = sizeof(int64_t) * (size_t)nblocks;
-    if ((rc = ws_ensure(c, WS_META, 2 * bb))) return rc;
+    if ((rc = ws_ensure(c, WS_LUFS, 2 * bb))) return rc;
     if ((rc = ws_ensure(c, WS_SCR2, sizeof(double) * (size_t)C * nblocks))) return rc;
-    Pinned* pin;
-    if ((rc = pinned_acquire(c, 2 * bb, &pin))) return rc;
-    memcpy(pin->host, lo, bb);
-    memcpy((char*)pin->host + bb, hi, bb);
-    HIPCHK(hipMemcpyAsync(c->ws[WS_META], pin->host, 2 * bb, hipMemcpyHostToDevice, stream));
-    HIPCHK(hipEventRecord(pin->ev, stream));
-    pin->pending = true;
+    // block bounds: uploaded only when they differ from the previous call's (same T / rate / block size -> same bounds)
+    if (c->lufs_bounds.size() != 2 * (size_t)nblocks || memcmp(c->lufs_bounds.data(), lo, bb) != 0 ||
+        memcmp(c->lufs_bounds.data() + nblocks, hi, bb) != 0 || c->lufs_bounds_dev != c->ws[WS_LUFS]) {
+        Pinned* pin;
+        if ((rc = pinned_acquire(c, 2 * bb, &pin))) return rc;
+        memcpy(pin->host, lo, bb);
+        memcpy((char*)pin->host + bb, hi, bb);
+        HIPCHK(hipMemcpyAsync(c->ws[WS_LUFS], pin->host, 2 * bb, hipMemcpyHostToDevice, stream));
+        HIPCHK(hipEventRecord(pin->ev, stream));
+        pin->pending = true;
+        c->lufs_bounds.assign(lo, lo + nblocks);
+        c->lufs_bounds.insert(c->lufs_bounds.end(), hi, hi + nblocks);
+        c->lufs_bounds_dev = c->ws[WS_LUFS];
+    }
     const int nthreads = C * nchunks;
     double* states = (double*)c->ws[WS_SCR];
-    double* gstate = states + 4 * (size_t)C * nchunks;
+    double* energy = (double*)c->ws[WS_FILT];
     hipLaunchKernelGGL(k_kw_state, dim3((nthreads + 255) / 256), dim3(256), 0, stream, (const float*)da, T, C, st, sc, k, nchunks, states);
-    hipLaunchKernelGGL(k_kw_groups<0>, dim3((C * ngroups + 63) / 64), dim3(64), 0, stream, k, C, nchunks, ngroups, states, gstate);
-    hipLaunchKernelGGL(k_kw_scan_groups, dim3(1), dim3(64), 0, stream, k, C, ngroups, gstate);
-    hipLaunchKernelGGL(k_kw_groups<1>, dim3((C * ngroups + 63) / 64), dim3(64), 0, stream, k, C, nchunks, ngroups, states, gstate);
-    hipLaunchKernelGGL(k_kw_apply, dim3((nthreads + 255) / 256), dim3(256), 0, stream, (const float*)da, T, C, st, sc, k, nchunks,
-                       (const double*)states, (double*)c->ws[WS_FILT]);
-    hipLaunchKernelGGL(k_block_power, dim3(nblocks, C), dim3(256), 0, stream, (const double*)c->ws[WS_FILT], T,
-                       (const int64_t*)c->ws[WS_META], (const int64_t*)((const char*)c->ws[WS_META] + bb), nblocks, 1.0 / norm,
-                       (double*)c->ws[WS_SCR2]);
+    hipLaunchKernelGGL(k_kw_scan, dim3(C), dim3(256), 0, stream, k, nchunks, ngroups, gsz, states);
+    hipLaunchKernelGGL(k_kw_energy, dim3((nthreads + 255) / 256), dim3(256), 0, stream, (const float*)da, T, C, st, sc, k, nchunks,
+                       (const double*)states, energy);
+    hipLaunchKernelGGL(k_block_power_chunks, dim3(nblocks, C), dim3(64), 0, stream, (const float*)da, T, st, sc, k, nchunks,
+                       (const double*)states, (const double*)energy, (const int64_t*)c->ws[WS_LUFS],
+                       (const int64_t*)((const char*)c->ws[WS_LUFS] + bb), nblocks, 1.0 / norm, (double*)c->ws[WS_SCR2]);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(z_out, c->ws[WS_SCR2], sizeof(double) * (size_t)C * nblocks, hipMemcpyDeviceToHost, stream));
     HIPCHK(hipStreamSynchronize(stream));
@@ -1194,15 +1261,15 @@ int ss_scale_f32(const float* in, float* out, int64_t n, float gain, double* sum
         if ((rc = ws_ensure(c, WS_X, sizeof(float) * (size_t)n))) return rc;
         dout = (float*)c->ws[WS_X];
     }
-    hipLaunchKernelGGL(k_scale, dim3(grid_for(n)), dim3(256), 0, stream, (const float*)din, dout, n, gain);
-    HIPCHK(hipGetLastError());
-    if (sums_out) {
-        const int nb = grid_for(n, 512);
+    if (!sums_out) {
+        hipLaunchKernelGGL(k_scale, dim3(grid_for(n)), dim3(256), 0, stream, (const float*)din, dout, n, gain);
+        HIPCHK(hipGetLastError());
+    } else {
+        const int nb = grid_for(n, 1024);
         if ((rc = ws_ensure(c, WS_SCR, sizeof(double) * (size_t)nb * 2))) return rc;
         if ((rc = ws_ensure(c, WS_SCR2, sizeof(double) * 2))) return rc;
         double* part = (double*)c->ws[WS_SCR];
-        hipLaunchKernelGGL(k_partial_sum<1>, dim3(nb, 1), dim3(256), 0, stream, (const float*)dout, n, part);
-        hipLaunchKernelGGL(k_partial_sum<1>, dim3(nb, 1), dim3(256), 0, stream, (const float*)din, n, part + nb);
+        hipLaunchKernelGGL(k_scale_sums, dim3(nb), dim3(256), 0, stream, (const float*)din, dout, n, gain, part);
         hipLaunchKernelGGL(k_final_sum, dim3(2), dim3(64), 0, stream, (const double*)part, nb, (double*)c->ws[WS_SCR2]);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(sums_out, c->ws[WS_SCR2], sizeof(double) * 2, hipMemcpyDeviceToHost, stream));

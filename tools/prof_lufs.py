@@ -1,0 +1,17 @@
+#!/usr/bin/env python3
+"""GPU box: time the loudness path (row U) on a config-2 sized stem; run under rocprofv3 --kernel-trace --stats for the kernel split."""
+import sys, time
+import numpy as np, torch
+sys.path.insert(0, ".")
+from sonicsim_amd import SonicSim_audio as A, ops
+ops.init(0)
+y = (0.05 * torch.randn(8, 960000, device="cuda:0")).contiguous()
+np.random.seed(1)
+for _ in range(2):
+    A.get_lufs_norm_audio(y, 16000, -17, allow_many_channels=True, channel_first=True)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(10):
+    A.get_lufs_norm_audio(y, 16000, -17, allow_many_channels=True, channel_first=True)
+torch.cuda.synchronize()
+print("lufs_norm ms/call", (time.perf_counter() - t0) / 10 * 1e3)
