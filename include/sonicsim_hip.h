@@ -128,6 +128,16 @@ int ss_kweighted_block_power_f32(const float* audio, int64_t T, int32_t C, const
 int ss_scale_f32(const float* in, float* out, int64_t n, float gain, double* sums_out, uint32_t flags,
                  void* stream);
 
+/* lufs_norm in ONE call (SonicSim_audio.py:68-81 incl. pyloudnorm's Meter.integrated_loudness gating and
+ * normalize.loudness): block powers as above, the BS.1770-4 two-stage gating and the gain on the device,
+ * out = (float)gain * audio.  weights[C] (HOST) are the channel weights G; target_lufs is the drawn class
+ * loudness.  result (HOST, 4 doubles): {integrated loudness (-inf if no block survives the gates; the gain
+ * then uses -40 like the reference), linear gain, sum(out), sum(audio)}.  One synchronisation at the end. */
+int ss_lufs_norm_f32(const float* audio, float* out, int64_t T, int32_t C, const double* coef,
+                     const int64_t* lo, const int64_t* hi, int32_t nblocks, double block_norm,
+                     const double* weights, double target_lufs, double* result, uint32_t flags,
+                     void* stream);
+
 /* ---- measurement hooks (bench.py): HIP-event timing of the dominant kernels on their own stream.
  * kind 0 = overlap-save render kernel (one parity pass = one launch), 1 = input-spectra kernel,
  * 2 = direct-form kernel.  ss_prof_read synchronises, then returns count and total milliseconds

@@ -93,6 +93,13 @@ def k_weighting_coefficients(rate: float) -> np.ndarray:
     return np.array(rows, dtype=np.float64)
 
 
+@functools.lru_cache(maxsize=16)
+def _kw_coef(rate: float) -> np.ndarray:
+    c = k_weighting_coefficients(rate)
+    c.setflags(write=False)
+    return c
+
+
 @functools.lru_cache(maxsize=64)
 def gating_blocks(num_samples: int, rate: float, block_size: float):
     """Block bounds exactly as pyloudnorm forms them: ``int(T_g * (j * step) * rate)`` and
@@ -124,10 +131,8 @@ def _gated_loudness(z: np.ndarray, weights) -> float:
         return float("-inf")
 
 
-def integrated_loudness(data, rate: float, block_size: float = 0.4, allow_many_channels: bool = False,
-                        channel_first: bool = False) -> float:
-    """pyloudnorm ``Meter(rate, block_size=...).integrated_loudness(data)``; data (T,) or (T, C).
-    ``channel_first=True`` (extension) takes (C, T) -- the layout the renderer produces -- without a transpose."""
+def _meter_args(data, rate: float, block_size: float, allow_many_channels: bool, channel_first: bool):
+    """pyloudnorm's input checks (util.valid_audio) + the block bounds / channel weights the device path needs."""
     is_t = hasattr(data, "dtype") and str(data.dtype).startswith("torch")
     if not is_t:
         data = np.asarray(data)
@@ -146,22 +151,29 @@ def integrated_loudness(data, rate: float, block_size: float = 0.4, allow_many_c
     if n < block_size * rate:
         raise ValueError("Audio must have length greater than the block size.")
     lo, hi = gating_blocks(n, rate, block_size)
-    z = ops.kweighted_block_power(data, k_weighting_coefficients(rate), lo, hi, block_size * rate,
-                                  layout_tc=not (channel_first and ndim == 2))
     weights = G_WEIGHTS if nch <= 5 else (1.0,) * nch
+    return data, lo, hi, weights, not (channel_first and ndim == 2)
+
+
+def integrated_loudness(data, rate: float, block_size: float = 0.4, allow_many_channels: bool = False,
+                        channel_first: bool = False) -> float:
+    """pyloudnorm ``Meter(rate, block_size=...).integrated_loudness(data)``; data (T,) or (T, C).
+    ``channel_first=True`` (extension) takes (C, T) -- the layout the renderer produces -- without a transpose."""
+    data, lo, hi, weights, layout_tc = _meter_args(data, rate, block_size, allow_many_channels, channel_first)
+    z = ops.kweighted_block_power(data, k_weighting_coefficients(rate), lo, hi, block_size * rate, layout_tc=layout_tc)
     return _gated_loudness(z, weights)
 
 
 def lufs_norm(data, sr, norm=-6, allow_many_channels: bool = False, channel_first: bool = False):
-    """SonicSim_audio.py:68-81.  data (T, C) (or (T,)).  Returns (normalised data, gain)."""
+    """SonicSim_audio.py:68-81.  data (T, C) (or (T,)).  Returns (normalised data, gain).
+    Measurement, gating, gain and scaling run in one device call (ops.lufs_norm) with one synchronisation."""
     nsamp = data.shape[-1] if (channel_first and data.ndim == 2) else len(data)
     block_size = 0.4 if nsamp / sr >= 0.4 else nsamp / sr
-    loudness = integrated_loudness(data, sr, block_size, allow_many_channels=allow_many_channels, channel_first=channel_first)
+    data, lo, hi, weights, layout_tc = _meter_args(data, sr, block_size, allow_many_channels, channel_first)
+    norm_data, loudness, _linear, n, d = ops.lufs_norm(data, _kw_coef(float(sr)), lo, hi, block_size * sr, weights, norm,
+                                                       layout_tc=layout_tc)
     if math.isinf(loudness):
-        loudness = -40
         print("loudness is inf")
-    linear = float(np.power(10.0, (norm - loudness) / 20.0))       # pyln.normalize.loudness
-    norm_data, (n, d) = ops.scale(data, linear, want_sums=True)
     gain = n / d if d else 0.0
     return norm_data, gain
 

@@ -211,24 +211,54 @@ __global__ __launch_bounds__(256) void k_partial_sum(const float* __restrict__ x
     if (threadIdx.x == 0) partial[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = (sw[0] + sw[1]) + (sw[2] + sw[3]);
 }
 // fixed-order final sum: lane l adds partial[l], partial[l + 64], ... then a butterfly over the 64 lanes (deterministic)
+#ifdef SS_DEBUG_CLK
+__device__ unsigned long long g_dbg_clk[8][2][256];
+#define DBG_CLK(kid, which) do { if (threadIdx.x == 0) { const int wg_ = blockIdx.x + gridDim.x * blockIdx.y; if (wg_ < 256) g_dbg_clk[kid][which][wg_] = wall_clock64(); } } while (0)
+#else
+#define DBG_CLK(kid, which) do {} while (0)
+#endif
 __global__ __launch_bounds__(64) void k_final_sum(const double* __restrict__ partial, int nb, double* __restrict__ out) {
+    DBG_CLK(3, 0);
     double s = 0.0;
     for (int i = threadIdx.x; i < nb; i += 64) s += partial[(int64_t)blockIdx.x * nb + i];
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
     if (threadIdx.x == 0) out[blockIdx.x] = s;
+    DBG_CLK(3, 1);
 }
-// out = gain * in with the float64 partial sums of out and in in the same pass (pyloudnorm.normalize.loudness + :78-79)
+// out = gain * in with the float64 partial sums of out and in in the same pass (pyloudnorm.normalize.loudness + :78-79).
+// gain_dev != nullptr: the gain is the float64 the gating kernel left on the device (rounded to float32 like the host path).
 __global__ __launch_bounds__(256) void k_scale_sums(const float* __restrict__ in, float* __restrict__ out, int64_t n, float gain,
-                                                    double* __restrict__ partial /*[2][grid]*/) {
+                                                    const double* __restrict__ gain_dev, double* __restrict__ partial /*[2][grid]*/) {
     __shared__ double sw[2][4];
+    if (gain_dev) gain = (float)*gain_dev;
     double so = 0.0, si = 0.0;
-    const int64_t stride = (int64_t)gridDim.x * 256;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
-        const float v = in[i];
-        const float o = gain * v;
-        out[i] = o;
-        so += (double)o;
-        si += (double)v;
+    const int64_t stride = (int64_t)gridDim.x * 256, tid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if ((((uintptr_t)in | (uintptr_t)out) & 15) == 0) {
+        const int64_t n4 = n >> 2;
+        const float4* in4 = (const float4*)in;
+        float4* out4 = (float4*)out;
+        for (int64_t i = tid; i < n4; i += stride) {
+            const float4 v = in4[i];
+            float4 o;
+            o.x = gain * v.x; o.y = gain * v.y; o.z = gain * v.z; o.w = gain * v.w;
+            out4[i] = o;
+            so += ((double)o.x + (double)o.y) + ((double)o.z + (double)o.w);
+            si += ((double)v.x + (double)v.y) + ((double)v.z + (double)v.w);
+        }
+        for (int64_t i = (n4 << 2) + tid; i < n; i += stride) {
+            const float v = in[i], o = gain * v;
+            out[i] = o;
+            so += (double)o;
+            si += (double)v;
+        }
+    } else {
+        for (int64_t i = tid; i < n; i += stride) {
+            const float v = in[i];
+            const float o = gain * v;
+            out[i] = o;
+            so += (double)o;
+            si += (double)v;
+        }
     }
     for (int o = 32; o > 0; o >>= 1) { so += __shfl_xor(so, o); si += __shfl_xor(si, o); }
     if ((threadIdx.x & 63) == 0) { sw[0][threadIdx.x >> 6] = so; sw[1][threadIdx.x >> 6] = si; }
@@ -312,10 +342,15 @@ __global__ __launch_bounds__(256) void k_scale(const float* __restrict__ in, flo
 // propagation across chunks with the 4x4 chunk transition matrix, (3) re-run from the true state.
 struct KwCoef {
     double b[2][3], a[2][3];
-    double Mx[16];   // state transition over one full chunk (row-major 4x4)
-    double Mg[16];   // state transition over one scan group (gsz chunks, chosen per call)
+    double Mp[13][16];   // Mp[i] = (state transition over one full chunk) ^ (2^i), row-major 4x4
+    double W[64][4];     // zero-state END state of a full chunk as a linear map of its samples: z = sum_t W[t] * x[t]
 };
-constexpr int KW_CHUNK = 128;    // samples per thread in the sample-level passes
+static_assert(sizeof(((KwCoef*)0)->W) == 64 * 4 * 8, "W is [KW_CHUNK][4]");
+constexpr int KW_CHUNK = 64;     // samples per thread in the sample-level passes (divides the 0.1 s block step at 16 kHz)
+constexpr int KW_ROW = KW_CHUNK + 4;   // floats per LDS row of the fused kernel: 16-lane groups of b128 accesses hit distinct banks
+constexpr int KW_SER = 8;        // chunks each scan thread walks serially
+constexpr int KW_TILE = 512;     // threads of the scan workgroup: one tile = KW_TILE * KW_SER chunks
+static_assert(KW_SER == 8 && KW_TILE == 512, "the scan's power indices (Mp[3+b], Mp[9+b], Mp[12]) assume 8 chunks/thread, 8 waves");
 
 __device__ __forceinline__ double kw_step(const KwCoef& k, double s[4], double xin) {
     const double y1 = k.b[0][0] * xin + s[0];
@@ -330,66 +365,301 @@ __device__ __forceinline__ void kw_matvec(const double* M, const double s[4], do
 #pragma unroll
     for (int r = 0; r < 4; ++r) o[r] = M[r * 4 + 0] * s[0] + M[r * 4 + 1] * s[1] + M[r * 4 + 2] * s[2] + M[r * 4 + 3] * s[3];
 }
+// visit the samples of one chunk in order; 16-byte loads when the chunk is whole, contiguous and aligned
+template <class F>
+__device__ __forceinline__ void kw_walk(const float* __restrict__ a, int64_t t0, int64_t t1, int64_t st, F&& f) {
+    if (st == 1 && t1 - t0 == KW_CHUNK && (((uintptr_t)(a + t0)) & 15) == 0) {
+        const float4* p = (const float4*)(a + t0);
+        float4 q[KW_CHUNK / 4];                         // the whole chunk in flight at once: one memory latency, not four
+#pragma unroll
+        for (int i = 0; i < KW_CHUNK / 4; ++i) q[i] = p[i];
+#pragma unroll
+        for (int i = 0; i < KW_CHUNK / 4; ++i) { f(q[i].x); f(q[i].y); f(q[i].z); f(q[i].w); }
+    } else {
+#pragma unroll 8
+        for (int64_t t = t0; t < t1; ++t) f(a[t * st]);
+    }
+}
 
+// zero-state end state of one chunk by its FIR form: 4 independent dot products (256 FMAs, no recurrence) instead of 64
+// dependent biquad steps (~700 float64 ops).  A short last chunk of n samples uses the rows W[64-n..63].
+__device__ __forceinline__ void kw_endstate(const float* __restrict__ a, int64_t t0, int64_t t1, int64_t st, const KwCoef& k, double v[4]) {
+    if (st == 1 && t1 - t0 == KW_CHUNK && (((uintptr_t)(a + t0)) & 15) == 0) {
+        const float4* p = (const float4*)(a + t0);
+        float4 q[KW_CHUNK / 4];
+#pragma unroll
+        for (int i = 0; i < KW_CHUNK / 4; ++i) q[i] = p[i];
+#pragma unroll
+        for (int i = 0; i < KW_CHUNK / 4; ++i) {
+            const double x0 = (double)q[i].x, x1 = (double)q[i].y, x2 = (double)q[i].z, x3 = (double)q[i].w;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                v[r] += k.W[4 * i][r] * x0 + k.W[4 * i + 1][r] * x1 + k.W[4 * i + 2][r] * x2 + k.W[4 * i + 3][r] * x3;
+        }
+    } else {
+        const int off = KW_CHUNK - (int)(t1 - t0);
+        for (int64_t t = t0; t < t1; ++t) {
+            const double x = (double)a[t * st];
+            const double* w = k.W[off + (int)(t - t0)];
+            v[0] += w[0] * x; v[1] += w[1] * x; v[2] += w[2] * x; v[3] += w[3] * x;
+        }
+    }
+}
 // pass 1: zero-state response of every chunk -> its end state z
 __global__ __launch_bounds__(256) void k_kw_state(const float* __restrict__ audio, int64_t T, int C, int64_t st, int64_t sc,
-                                                  KwCoef k, int nchunks, double* __restrict__ states /*[C][nchunks][4]*/) {
+                                                  const KwCoef* __restrict__ kp, int nchunks, double* __restrict__ states /*[C][nchunks][4]*/) {
+    const KwCoef& k = *kp;
     const int id = blockIdx.x * 256 + threadIdx.x;
     if (id >= C * nchunks) return;
     const int c = id / nchunks, ch = id - c * nchunks;
     double s[4] = {0, 0, 0, 0};
     const int64_t t0 = (int64_t)ch * KW_CHUNK;
     const int64_t t1 = t0 + KW_CHUNK < T ? t0 + KW_CHUNK : T;
-    const float* a = audio + c * sc;
-#pragma unroll 8
-    for (int64_t t = t0; t < t1; ++t) kw_step(k, s, (double)a[t * st]);
+    kw_endstate(audio + c * sc, t0, t1, st, k, s);
     double* o = states + ((int64_t)c * nchunks + ch) * 4;
     o[0] = s[0]; o[1] = s[1]; o[2] = s[2]; o[3] = s[3];
 }
-// passes 2-4 in ONE launch: workgroup = channel, thread = group of gsz chunks.  (a) end state of every group from a zero
-// group state, (b) thread 0 propagates the group states serially (few dozen groups), (c) every thread re-walks its group from
-// the true start state and rewrites states[] := start state of every chunk.
-__global__ __launch_bounds__(256) void k_kw_scan(KwCoef k, int nchunks, int ngroups, int gsz, double* __restrict__ states) {
-    __shared__ double gs[256][4];
-    const int c = blockIdx.x, g = threadIdx.x;
+// pass 2: states[] := TRUE start state of every chunk.  The chunk recurrence s' = M s + z has the same M for every chunk, so
+// an inclusive scan only needs powers of M.  Two launches, both with workgroup = (tile of 4096 chunks, channel) and
+// thread = KW_SER consecutive chunks:
+//   k_kw_scan_local: (a) serial walk of the thread's chunks from a zero state, (b) Hillis-Steele inside each wave (6 shuffle
+//     steps, spans M^8 .. M^256), (c) Hillis-Steele over the 8 wave totals (wave 0), (d) thread start = previous lane's
+//     prefix + (M^8)^lane * (wave carry-in), serial walk again storing the chunk start states RELATIVE TO A ZERO TILE START,
+//     plus the tile's end state tot[c][tile].
+//   k_kw_scan_carry: tile carry = sum over the earlier tiles' totals (a handful of M^4096 steps), added to every chunk of the
+//     tile as M^n * carry, n = chunk index in the tile = i + 8*lane + 512*wave.
+// ptab: [0..63] = (M^8)^lane, [64..71] = (M^512)^wave (row-major 4x4 each).
+__global__ __launch_bounds__(KW_TILE) void k_kw_scan_local(const KwCoef* __restrict__ kp, int nchunks, int ntiles, const double* __restrict__ ptab,
+                                                           double* __restrict__ states, double* __restrict__ tot /*[C][ntiles][4]*/) {
+    DBG_CLK(0, 0);
+    __shared__ double wt[KW_TILE / 64][4];
+    __shared__ double mp[13][16];                     // the powers of M: one global round trip instead of one scalar-cache miss per use
+    if (threadIdx.x < 13 * 16) (&mp[0][0])[threadIdx.x] = (&kp->Mp[0][0])[threadIdx.x];
+    const int c = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     double* st = states + (int64_t)c * nchunks * 4;
-    const int c0 = g * gsz, c1 = c0 + gsz < nchunks ? c0 + gsz : nchunks;
-    double s[4] = {0, 0, 0, 0};
-    if (g < ngroups) {
-        for (int ch = c0; ch < c1; ++ch) {
-            double nx[4];
-            kw_matvec(k.Mx, s, nx);
-            s[0] = nx[0] + st[ch * 4 + 0]; s[1] = nx[1] + st[ch * 4 + 1]; s[2] = nx[2] + st[ch * 4 + 2]; s[3] = nx[3] + st[ch * 4 + 3];
-        }
-        gs[g][0] = s[0]; gs[g][1] = s[1]; gs[g][2] = s[2]; gs[g][3] = s[3];
+    const int c0 = tile * (KW_TILE * KW_SER) + tid * KW_SER;
+    double v[4] = {0, 0, 0, 0}, m[4], u[4];
+    double2 z[KW_SER][2];                             // the thread's chunk end states: all loads in flight together
+#pragma unroll
+    for (int i = 0; i < KW_SER; ++i) {
+        const int ch = c0 + i < nchunks ? c0 + i : nchunks - 1;
+        const double2* q = (const double2*)(st + (int64_t)ch * 4);
+        z[i][0] = q[0];
+        z[i][1] = q[1];
+    }
+    double P[16];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const double2 q = ((const double2*)(ptab + lane * 16))[i];
+        P[2 * i] = q.x;
+        P[2 * i + 1] = q.y;
     }
     __syncthreads();
-    if (g == 0) {
-        double a[4] = {0, 0, 0, 0};
-        for (int q = 0; q < ngroups; ++q) {
-            const double z0 = gs[q][0], z1 = gs[q][1], z2 = gs[q][2], z3 = gs[q][3];
-            gs[q][0] = a[0]; gs[q][1] = a[1]; gs[q][2] = a[2]; gs[q][3] = a[3];
-            double nx[4];
-            kw_matvec(k.Mg, a, nx);
-            a[0] = nx[0] + z0; a[1] = nx[1] + z1; a[2] = nx[2] + z2; a[3] = nx[3] + z3;
+#pragma unroll
+    for (int i = 0; i < KW_SER; ++i) {
+        if (c0 + i >= nchunks) z[i][0] = z[i][1] = make_double2(0.0, 0.0);
+        kw_matvec(mp[0], v, m);
+        v[0] = m[0] + z[i][0].x; v[1] = m[1] + z[i][0].y; v[2] = m[2] + z[i][1].x; v[3] = m[3] + z[i][1].y;
+    }
+#pragma unroll
+    for (int b = 0; b < 6; ++b) {
+        const int d = 1 << b;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) u[r] = __shfl_up(v[r], d, 64);
+        kw_matvec(mp[3 + b], u, m);
+        if (lane >= d) { v[0] += m[0]; v[1] += m[1]; v[2] += m[2]; v[3] += m[3]; }
+    }
+    if (lane == 63) { wt[w][0] = v[0]; wt[w][1] = v[1]; wt[w][2] = v[2]; wt[w][3] = v[3]; }
+    __syncthreads();
+    if (w == 0) {
+        double t[4] = {0, 0, 0, 0};
+        if (lane < KW_TILE / 64) { t[0] = wt[lane][0]; t[1] = wt[lane][1]; t[2] = wt[lane][2]; t[3] = wt[lane][3]; }
+#pragma unroll
+        for (int b = 0; (1 << b) < KW_TILE / 64; ++b) {
+            const int d = 1 << b;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) u[r] = __shfl_up(t[r], d, 64);
+            kw_matvec(mp[9 + b], u, m);
+            if (lane >= d) { t[0] += m[0]; t[1] += m[1]; t[2] += m[2]; t[3] += m[3]; }
+        }
+        if (lane < KW_TILE / 64) { wt[lane][0] = t[0]; wt[lane][1] = t[1]; wt[lane][2] = t[2]; wt[lane][3] = t[3]; }   // END state of wave `lane`
+        if (lane == KW_TILE / 64 - 1) {
+            double* o = tot + ((int64_t)c * ntiles + tile) * 4;
+            o[0] = t[0]; o[1] = t[1]; o[2] = t[2]; o[3] = t[3];
         }
     }
     __syncthreads();
-    if (g < ngroups) {
-        s[0] = gs[g][0]; s[1] = gs[g][1]; s[2] = gs[g][2]; s[3] = gs[g][3];
-        for (int ch = c0; ch < c1; ++ch) {
-            const double z0 = st[ch * 4 + 0], z1 = st[ch * 4 + 1], z2 = st[ch * 4 + 2], z3 = st[ch * 4 + 3];
-            st[ch * 4 + 0] = s[0]; st[ch * 4 + 1] = s[1]; st[ch * 4 + 2] = s[2]; st[ch * 4 + 3] = s[3];
-            double nx[4];
-            kw_matvec(k.Mx, s, nx);
-            s[0] = nx[0] + z0; s[1] = nx[1] + z1; s[2] = nx[2] + z2; s[3] = nx[3] + z3;
-        }
+    double cw[4], S[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        cw[r] = w == 0 ? 0.0 : wt[w > 0 ? w - 1 : 0][r];
+        u[r] = __shfl_up(v[r], 1, 64);
+        if (lane == 0) u[r] = 0.0;
     }
+    kw_matvec(P, cw, m);
+    S[0] = u[0] + m[0]; S[1] = u[1] + m[1]; S[2] = u[2] + m[2]; S[3] = u[3] + m[3];
+#pragma unroll
+    for (int i = 0; i < KW_SER; ++i) {
+        const int ch = c0 + i;
+        if (ch < nchunks) {
+            double2* q = (double2*)(st + (int64_t)ch * 4);
+            q[0] = make_double2(S[0], S[1]);
+            q[1] = make_double2(S[2], S[3]);
+        }
+        kw_matvec(mp[0], S, m);
+        S[0] = m[0] + z[i][0].x; S[1] = m[1] + z[i][0].y; S[2] = m[2] + z[i][1].x; S[3] = m[3] + z[i][1].y;
+    }
+    DBG_CLK(0, 1);
 }
-// pass 5': re-run every chunk from its true start state and keep only the chunk's K-weighted energy (float64): the gating
+__global__ __launch_bounds__(KW_TILE) void k_kw_scan_carry(const KwCoef* __restrict__ kp, int nchunks, int ntiles, const double* __restrict__ ptab,
+                                                           double* __restrict__ states, const double* __restrict__ tot) {
+    DBG_CLK(1, 0);
+    const KwCoef& k = *kp;
+    const int c = blockIdx.y, tile = blockIdx.x + 1, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;   // tile 0 has no carry
+    double* st = states + (int64_t)c * nchunks * 4;
+    const int c0 = tile * (KW_TILE * KW_SER) + tid * KW_SER;
+    double carry[4] = {0, 0, 0, 0}, m[4], x[4], y[4];
+    for (int i = 0; i < tile; ++i) {
+        const double* t = tot + ((int64_t)c * ntiles + i) * 4;
+        kw_matvec(k.Mp[12], carry, m);
+        carry[0] = m[0] + t[0]; carry[1] = m[1] + t[1]; carry[2] = m[2] + t[2]; carry[3] = m[3] + t[3];
+    }
+    double2 z[KW_SER][2];                             // the thread's chunk states: all loads in flight together
+#pragma unroll
+    for (int i = 0; i < KW_SER; ++i) {
+        const int ch = c0 + i < nchunks ? c0 + i : nchunks - 1;
+        const double2* q = (const double2*)(st + (int64_t)ch * 4);
+        z[i][0] = q[0];
+        z[i][1] = q[1];
+    }
+    double Q[16], P[16];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const double2 a = ((const double2*)(ptab + (64 + w) * 16))[i], b = ((const double2*)(ptab + lane * 16))[i];
+        Q[2 * i] = a.x; Q[2 * i + 1] = a.y;
+        P[2 * i] = b.x; P[2 * i + 1] = b.y;
+    }
+    kw_matvec(Q, carry, x);
+    kw_matvec(P, x, y);
+#pragma unroll
+    for (int i = 0; i < KW_SER; ++i) {
+        const int ch = c0 + i;
+        if (ch < nchunks) {
+            double2* q = (double2*)(st + (int64_t)ch * 4);
+            q[0] = make_double2(z[i][0].x + y[0], z[i][0].y + y[1]);
+            q[1] = make_double2(z[i][1].x + y[2], z[i][1].y + y[3]);
+        }
+        kw_matvec(k.Mp[0], y, m);
+        y[0] = m[0]; y[1] = m[1]; y[2] = m[2]; y[3] = m[3];
+    }
+    DBG_CLK(1, 1);
+}
+// Passes 1-3 in ONE launch when the filter forgets fast enough (every practical K-weighting: the slowest pole, 38 Hz, decays
+// below 1e-20 within H <= 256 chunks): workgroup = (NT - H new chunks + H history chunks, channel), thread = chunk.  The
+// history chunks start from a zero state; what that ignores is below 1e-20 of the state by the first new chunk, far under
+// float64 resolution.  Phase 1: zero-state walk -> chunk end state.  Phase 2: Hillis-Steele inside each wave (M^1..M^32) and
+// over the wave totals (M^64..), chunk start = previous lane's prefix + M^lane * (wave carry-in).  Phase 3: the new chunks
+// walk again from their start state and keep their energy (+ the start state, for k_block_power_chunks' edge chunks).
+template <int NT>
+__global__ __launch_bounds__(NT) void k_kw_fused(const float* __restrict__ audio, int64_t T, int64_t st, int64_t sc,
+                                                 const KwCoef* __restrict__ kp, const double* __restrict__ plane /*[64][16] = M^lane*/,
+                                                 int nchunks, int H, double* __restrict__ states, double* __restrict__ energy) {
+    constexpr int NW = NT / 64;
+    __shared__ float xs[NW][64][KW_ROW];              // the wave's 64 chunks, one padded row per chunk
+    __shared__ double wt[NW][4];
+    __shared__ double mp[10][16];
+    const KwCoef& k = *kp;
+    const int c = blockIdx.y, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int ch = blockIdx.x * (NT - H) - H + tid;
+    if (tid < 160) (&mp[0][0])[tid] = (&kp->Mp[0][0])[tid];
+    double P[16];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const double2 q = ((const double2*)(plane + lane * 16))[i];
+        P[2 * i] = q.x;
+        P[2 * i + 1] = q.y;
+    }
+    const bool live = ch >= 0 && ch < nchunks;
+    const float* a = audio + c * sc;
+    // the wave's 64 chunks are 16 KiB of contiguous samples: fetch them with fully coalesced 16-byte loads and hand each
+    // thread its chunk through LDS (a per-thread walk of global memory touches 64 cache lines per load instruction)
+    const int chw = ch - lane;
+    const int64_t tw = (int64_t)chw * KW_CHUNK;
+    const bool fast = st == 1 && chw >= 0 && tw + 64 * KW_CHUNK <= T && (((uintptr_t)(a + tw)) & 15) == 0;
+    if (fast) {
+        const float4* g = (const float4*)(a + tw);
+        float4 q[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) q[j] = g[j * 64 + lane];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) *(float4*)&xs[w][4 * j + (lane >> 4)][(lane & 15) * 4] = q[j];
+    }
+    const float* row = &xs[w][lane][0];
+    const int64_t t0 = (int64_t)ch * KW_CHUNK;
+    const int64_t t1 = t0 + KW_CHUNK < T ? t0 + KW_CHUNK : T;
+    double v[4] = {0, 0, 0, 0}, m[4], u[4];
+    DBG_CLK(0, 0);
+    __syncthreads();
+    if (live) {
+        if (fast) kw_endstate(row, 0, KW_CHUNK, 1, k, v);
+        else kw_endstate(a, t0, t1, st, k, v);
+    }
+    DBG_CLK(1, 0);
+    DBG_CLK(1, 1);
+#pragma unroll
+    for (int b = 0; b < 6; ++b) {
+        const int d = 1 << b;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) u[r] = __shfl_up(v[r], d, 64);
+        kw_matvec(mp[b], u, m);
+        if (lane >= d) { v[0] += m[0]; v[1] += m[1]; v[2] += m[2]; v[3] += m[3]; }
+    }
+    if (lane == 63) { wt[w][0] = v[0]; wt[w][1] = v[1]; wt[w][2] = v[2]; wt[w][3] = v[3]; }
+    __syncthreads();
+    if (w == 0) {
+        double t[4] = {0, 0, 0, 0};
+        if (lane < NW) { t[0] = wt[lane][0]; t[1] = wt[lane][1]; t[2] = wt[lane][2]; t[3] = wt[lane][3]; }
+#pragma unroll
+        for (int b = 0; (1 << b) < NW; ++b) {
+            const int d = 1 << b;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) u[r] = __shfl_up(t[r], d, 64);
+            kw_matvec(mp[6 + b], u, m);
+            if (lane >= d) { t[0] += m[0]; t[1] += m[1]; t[2] += m[2]; t[3] += m[3]; }
+        }
+        if (lane < NW) { wt[lane][0] = t[0]; wt[lane][1] = t[1]; wt[lane][2] = t[2]; wt[lane][3] = t[3]; }   // END state of wave `lane`
+    }
+    __syncthreads();
+    double cw[4], S[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        cw[r] = w == 0 ? 0.0 : wt[w > 0 ? w - 1 : 0][r];
+        u[r] = __shfl_up(v[r], 1, 64);
+        if (lane == 0) u[r] = 0.0;
+    }
+    kw_matvec(P, cw, m);
+    S[0] = u[0] + m[0]; S[1] = u[1] + m[1]; S[2] = u[2] + m[2]; S[3] = u[3] + m[3];
+    DBG_CLK(7, 0);
+    if (live && tid >= H) {
+        double2* q = (double2*)(states + ((int64_t)c * nchunks + ch) * 4);
+        q[0] = make_double2(S[0], S[1]);
+        q[1] = make_double2(S[2], S[3]);
+        double e = 0.0;
+        auto f = [&](float x) {
+            const double y = kw_step(k, S, (double)x);
+            e += y * y;
+        };
+        if (fast) kw_walk(row, 0, KW_CHUNK, 1, f);
+        else kw_walk(a, t0, t1, st, f);
+        energy[(int64_t)c * nchunks + ch] = e;
+    }
+    DBG_CLK(0, 1);
+}
+// pass 3: re-run every chunk from its true start state and keep only the chunk's K-weighted energy (float64): the gating
 // blocks are sums of whole chunks plus two partial edge chunks (k_block_power_chunks), so the filtered signal is never stored
-__global__ __launch_bounds__(256) void k_kw_energy(const float* __restrict__ audio, int64_t T, int C, int64_t st, int64_t sc, KwCoef k,
+__global__ __launch_bounds__(256) void k_kw_energy(const float* __restrict__ audio, int64_t T, int C, int64_t st, int64_t sc, const KwCoef* __restrict__ kp,
                                                    int nchunks, const double* __restrict__ states, double* __restrict__ energy /*[C][nchunks]*/) {
+    const KwCoef& k = *kp;
     const int id = blockIdx.x * 256 + threadIdx.x;
     if (id >= C * nchunks) return;
     const int c = id / nchunks, ch = id - c * nchunks;
@@ -397,56 +667,125 @@ __global__ __launch_bounds__(256) void k_kw_energy(const float* __restrict__ aud
     double s[4] = {z[0], z[1], z[2], z[3]};
     const int64_t t0 = (int64_t)ch * KW_CHUNK;
     const int64_t t1 = t0 + KW_CHUNK < T ? t0 + KW_CHUNK : T;
-    const float* a = audio + c * sc;
     double e = 0.0;
-#pragma unroll 8
-    for (int64_t t = t0; t < t1; ++t) {
-        const double v = kw_step(k, s, (double)a[t * st]);
+    kw_walk(audio + c * sc, t0, t1, st, [&](float x) {
+        const double v = kw_step(k, s, (double)x);
         e += v * v;
-    }
+    });
     energy[(int64_t)c * nchunks + ch] = e;
 }
 // z[c][j] = (1/norm) * sum_{t in [lo_j, hi_j)} k(x_c)[t]^2 from the chunk energies: whole chunks are added in a fixed order by
 // the 64 lanes, the (at most two) partial edge chunks are re-filtered from their stored start state by lanes 0 and 1.
-__global__ __launch_bounds__(64) void k_block_power_chunks(const float* __restrict__ audio, int64_t T, int64_t st, int64_t sc, KwCoef k,
+__global__ __launch_bounds__(64) void k_block_power_chunks(const float* __restrict__ audio, int64_t T, int64_t st, int64_t sc, const KwCoef* __restrict__ kp,
                                                            int nchunks, const double* __restrict__ states, const double* __restrict__ energy,
                                                            const int64_t* __restrict__ lo, const int64_t* __restrict__ hi, int nblocks,
                                                            double inv_norm, double* __restrict__ z /*[C][nblocks]*/) {
+    const KwCoef& k = *kp;
     const int j = blockIdx.x, c = blockIdx.y;
     int64_t a = lo[j], b = hi[j];
     a = a < 0 ? 0 : a;
     b = b > T ? T : b;
+    __shared__ float eb[2][KW_CHUNK];
     double s = 0.0;
+    int64_t edge0 = -1, edge1 = -1;                                                // partial chunks (uniform over the wave)
     if (b > a) {
         const int64_t ca = a / KW_CHUNK, cb = (b - 1) / KW_CHUNK;                 // first / last chunk touched
         const int64_t cb_end = (cb + 1) * KW_CHUNK < T ? (cb + 1) * KW_CHUNK : T;
         const bool head_whole = a == ca * KW_CHUNK, tail_whole = b == cb_end;
         const double* e = energy + (int64_t)c * nchunks;
-        int64_t edge = -1;                                                        // chunk this lane re-filters (lanes 0 / 1 only)
         if (ca == cb) {
             if (head_whole && tail_whole) { if (threadIdx.x == 0) s += e[ca]; }
-            else if (threadIdx.x == 0) edge = ca;
+            else edge0 = ca;
         } else {
             const int64_t f0 = head_whole ? ca : ca + 1, f1 = tail_whole ? cb + 1 : cb;
             for (int64_t q = f0 + threadIdx.x; q < f1; q += 64) s += e[q];
-            if (threadIdx.x == 0 && !head_whole) edge = ca;
-            if (threadIdx.x == 1 && !tail_whole) edge = cb;
+            if (!head_whole) edge0 = ca;
+            if (!tail_whole) edge1 = cb;
         }
-        if (edge >= 0) {
+    }
+    const float* au = audio + c * sc;
+    for (int i = threadIdx.x; i < KW_CHUNK; i += 64) {                             // edge samples: one coalesced load each
+        const int64_t ta = edge0 * KW_CHUNK + i, tb = edge1 * KW_CHUNK + i;
+        eb[0][i] = (edge0 >= 0 && ta < T) ? au[ta * st] : 0.f;
+        eb[1][i] = (edge1 >= 0 && tb < T) ? au[tb * st] : 0.f;
+    }
+    __syncthreads();
+    {
+        const int64_t edge = threadIdx.x == 0 ? edge0 : (threadIdx.x == 1 ? edge1 : -1);
+        if (edge >= 0) {                                                           // lanes 0 / 1 re-filter their edge chunk
             const double* zz = states + ((int64_t)c * nchunks + edge) * 4;
             double sv[4] = {zz[0], zz[1], zz[2], zz[3]};
             const int64_t t0 = edge * KW_CHUNK;
             int64_t t1 = t0 + KW_CHUNK < T ? t0 + KW_CHUNK : T;
             t1 = t1 < b ? t1 : b;
-            const float* au = audio + c * sc;
+            const float* eb_ = eb[threadIdx.x];
+#pragma unroll 8
             for (int64_t t = t0; t < t1; ++t) {
-                const double v = kw_step(k, sv, (double)au[t * st]);
+                const double v = kw_step(k, sv, (double)eb_[t - t0]);
                 if (t >= a) s += v * v;
             }
         }
     }
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
     if (threadIdx.x == 0) z[(int64_t)c * nblocks + j] = inv_norm * s;
+}
+// BS.1770-4 two-stage gating (pyloudnorm.Meter.integrated_loudness) over z[C][nblocks], then the gain of lufs_norm
+// (SonicSim_audio.py:68-77): res[0] = integrated loudness (-inf when no block survives), res[1] = 10^((target - L)/20) with
+// L := -40 when the loudness is -inf (the reference's fallback).  One workgroup; wave w reduces channels w, w+4, ...
+__global__ __launch_bounds__(1024) void k_gate(const double* __restrict__ z, int C, int nblocks, const double* __restrict__ gw /*[C] channel weights*/, double target,
+                                               double* __restrict__ lbuf /*[nblocks] scratch*/, int use_lds, double* __restrict__ res) {
+    DBG_CLK(2, 0);
+    extern __shared__ double gsm[];                      // use_lds: [C][nblocks] copy of z, then [nblocks] block loudness
+    __shared__ double part[65];                          // [channel] sums over the kept blocks, [64] = kept-block count
+    __shared__ double rel_s;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    double* lb = use_lds ? gsm + (size_t)C * nblocks : lbuf;
+    const double* zz = use_lds ? gsm : z;
+    for (int j = tid; j < nblocks; j += 1024) {
+        double s = 0.0;
+        for (int c = 0; c < C; ++c) {
+            const double v = z[(int64_t)c * nblocks + j];
+            if (use_lds) gsm[(size_t)c * nblocks + j] = v;
+            s += gw[c] * v;
+        }
+        lb[j] = -0.691 + 10.0 * log10(s);
+    }
+    __syncthreads();
+    DBG_CLK(4, 0);
+    double loud = -INFINITY;
+    for (int stage = 0; stage < 2; ++stage) {
+        const double rel = stage ? rel_s : 0.0;
+        for (int c = w; c <= C; c += 16) {               // wave per channel; c == C: the kept-block count
+            double s = 0.0;
+#pragma unroll 4
+            for (int j = lane; j < nblocks; j += 64) {
+                const double l = lb[j];
+                const bool keep = stage ? (l > rel && l > -70.0) : (l >= -70.0);
+                const double zv = c < C ? zz[(int64_t)c * nblocks + j] : 1.0;
+                if (keep) s += zv;
+            }
+            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+            if (lane == 0) part[c < C ? c : 64] = s;
+        }
+        __syncthreads();
+        DBG_CLK(5, stage);
+        if (tid == 0) {
+            const double nk = part[64];
+            double acc = 0.0;
+            for (int c = 0; c < C; ++c) acc += gw[c] * (part[c] / nk);
+            const double l = -0.691 + 10.0 * log10(acc);
+            if (stage == 0) rel_s = nk > 0.0 ? l - 10.0 : NAN;
+            else loud = nk > 0.0 ? l : -INFINITY;
+        }
+        __syncthreads();
+        DBG_CLK(6, stage);
+    }
+    if (tid == 0) {
+        res[0] = loud;
+        const double used = isinf(loud) ? -40.0 : loud;
+        res[1] = pow(10.0, (target - used) / 20.0);
+    }
+    DBG_CLK(2, 1);
 }
 
 // =============================================================================================
@@ -472,7 +811,7 @@ int fail(int code, const char* fmt, ...) {
         if (e_ != hipSuccess) return fail(e_ == hipErrorOutOfMemory ? SS_ENOMEM : SS_EHIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
     } while (0)
 
-enum WsSlot { WS_XS, WS_PLAN, WS_BMIN, WS_BMAX, WS_X, WS_BANK, WS_IDX, WS_W, WS_Y, WS_SCR, WS_SCR2, WS_FILT, WS_META, WS_CNT, WS_LUFS, WS_COUNT };
+enum WsSlot { WS_XS, WS_PLAN, WS_BMIN, WS_BMAX, WS_X, WS_BANK, WS_IDX, WS_W, WS_Y, WS_SCR, WS_SCR2, WS_FILT, WS_META, WS_CNT, WS_LUFS, WS_RES, WS_KWP, WS_KWT, WS_GW, WS_COUNT };
 
 struct Pinned {
     void* host = nullptr;
@@ -518,6 +857,10 @@ struct Ctx {
     std::vector<int32_t> plan_scratch;
     std::vector<int64_t> lufs_bounds;     // block bounds currently resident in ws[WS_LUFS]
     void* lufs_bounds_dev = nullptr;
+    double kw_cached[12] = {0};           // biquad coefficients whose KwCoef + carry-power tables are resident in ws[WS_KWP]
+    double gw_cached[64] = {0};           // channel weights resident in ws[WS_GW]
+    void* gw_cached_dev = nullptr;
+    void* kw_cached_dev = nullptr;
     int num_cu = 0;
 };
 
@@ -1152,22 +1495,8 @@ int ss_mix_f32(float* speakers, int32_t S, const float* noises, int32_t N, int64
     return SS_OK;
 }
 
-int ss_kweighted_block_power_f32(const float* audio, int64_t T, int32_t C, const double* coef, const int64_t* lo,
-                                 const int64_t* hi, int32_t nblocks, double norm, double* z_out, uint32_t flags, void* stream_) {
-    if (!audio || T <= 0 || C < 1 || C > 64 || !coef || nblocks < 0 || (nblocks && (!lo || !hi)) || !z_out || !(norm > 0))
-        return fail(SS_EINVAL, "bad argument");
-    if (nblocks == 0) return SS_OK;
-    std::lock_guard<std::mutex> lk(g_mu);
-    Ctx* c;
-    int rc = get_ctx(&c);
-    if (rc) return rc;
-    hipStream_t stream = (hipStream_t)stream_;
-    if ((rc = stream_enter(c, stream))) return rc;
-    const void* da;
-    if ((rc = stage_in(c, WS_Y, audio, sizeof(float) * (size_t)C * T, (flags & SS_FLAG_DEVICE_PTR) != 0, stream, &da))) return rc;
-    const bool tc = (flags & SS_FLAG_LAYOUT_TC) != 0;
-    const int64_t st = tc ? C : 1, sc = tc ? 1 : T;
-    KwCoef k;
+// K-weighting coefficients -> KwCoef (normalised biquads + the powers of the chunk transition matrix the scan needs)
+static int kw_setup(const double* coef, KwCoef& k) {
     for (int s = 0; s < 2; ++s) {
         const double a0 = coef[s * 6 + 3];
         if (a0 == 0.0) return fail(SS_EINVAL, "a0 == 0");
@@ -1185,36 +1514,43 @@ int ss_kweighted_block_power_f32(const float* audio, int64_t T, int32_t C, const
             s[2] = k.b[1][1] * y1 - k.a[1][1] * y2 + s[3];
             s[3] = k.b[1][2] * y1 - k.a[1][2] * y2;
         }
-        for (int r = 0; r < 4; ++r) k.Mx[r * 4 + u] = s[r];
+        for (int r = 0; r < 4; ++r) k.Mp[0][r * 4 + u] = s[r];
     }
-    const int nchunks = (int)((T + KW_CHUNK - 1) / KW_CHUNK);
-    int gsz = (nchunks + 255) / 256;                     // chunks per scan thread: one workgroup of <= 256 threads per channel
-    if (gsz < 16) gsz = 16;
-    const int ngroups = (nchunks + gsz - 1) / gsz;
-    {   // Mg = Mx ^ gsz (square and multiply)
-        double R[16], A[16], Bm[16];
-        for (int i = 0; i < 16; ++i) R[i] = (i % 5 == 0) ? 1.0 : 0.0;
-        memcpy(A, k.Mx, sizeof(A));
-        auto mul = [&](const double* X, const double* Y, double* Z) {
-            for (int r = 0; r < 4; ++r)
-                for (int q = 0; q < 4; ++q) {
-                    double acc = 0;
-                    for (int m = 0; m < 4; ++m) acc += X[r * 4 + m] * Y[m * 4 + q];
-                    Z[r * 4 + q] = acc;
-                }
-        };
-        for (int e = gsz; e > 0; e >>= 1) {
-            if (e & 1) { mul(A, R, Bm); memcpy(R, Bm, sizeof(R)); }
-            mul(A, A, Bm);
-            memcpy(A, Bm, sizeof(A));
+    // W[t] = end state of a chunk whose only non-zero sample is x[t] = 1
+    for (int t = 0; t < KW_CHUNK; ++t) {
+        double s[4] = {0, 0, 0, 0};
+        for (int u = t; u < KW_CHUNK; ++u) {
+            const double xin = u == t ? 1.0 : 0.0;
+            const double y1 = k.b[0][0] * xin + s[0];
+            s[0] = k.b[0][1] * xin - k.a[0][1] * y1 + s[1];
+            s[1] = k.b[0][2] * xin - k.a[0][2] * y1;
+            const double y2 = k.b[1][0] * y1 + s[2];
+            s[2] = k.b[1][1] * y1 - k.a[1][1] * y2 + s[3];
+            s[3] = k.b[1][2] * y1 - k.a[1][2] * y2;
         }
-        memcpy(k.Mg, R, sizeof(R));
+        for (int r = 0; r < 4; ++r) k.W[t][r] = s[r];
     }
+    for (int i = 1; i < 13; ++i)                        // Mp[i] = Mp[i-1]^2
+        for (int r = 0; r < 4; ++r)
+            for (int q = 0; q < 4; ++q) {
+                double acc = 0;
+                for (int m = 0; m < 4; ++m) acc += k.Mp[i - 1][r * 4 + m] * k.Mp[i - 1][m * 4 + q];
+                k.Mp[i][r * 4 + q] = acc;
+            }
+    return SS_OK;
+}
+
+// device part of row U's measurement: leaves z[C][nblocks] (float64) in ws[WS_SCR2].  da is a device pointer.
+static int kw_block_power_dev(Ctx* c, const float* da, int64_t T, int32_t C, int64_t st, int64_t sc, const KwCoef& k, const int64_t* lo,
+                              const int64_t* hi, int32_t nblocks, double norm, hipStream_t stream) {
+    int rc;
+    if ((T + KW_CHUNK - 1) / KW_CHUNK > (int64_t)INT32_MAX / (4 * C)) return fail(SS_EINVAL, "audio too long");
+    const int nchunks = (int)((T + KW_CHUNK - 1) / KW_CHUNK);
     if ((rc = ws_ensure(c, WS_SCR, sizeof(double) * 4 * (size_t)C * nchunks))) return rc;
     if ((rc = ws_ensure(c, WS_FILT, sizeof(double) * (size_t)C * nchunks))) return rc;          // chunk energies
     const size_t bb = sizeof(int64_t) * (size_t)nblocks;
     if ((rc = ws_ensure(c, WS_LUFS, 2 * bb))) return rc;
-    if ((rc = ws_ensure(c, WS_SCR2, sizeof(double) * (size_t)C * nblocks))) return rc;
+    if ((rc = ws_ensure(c, WS_SCR2, sizeof(double) * ((size_t)C + 1) * nblocks))) return rc;   // z + the gate's per-block scratch
     // block bounds: uploaded only when they differ from the previous call's (same T / rate / block size -> same bounds)
     if (c->lufs_bounds.size() != 2 * (size_t)nblocks || memcmp(c->lufs_bounds.data(), lo, bb) != 0 ||
         memcmp(c->lufs_bounds.data() + nblocks, hi, bb) != 0 || c->lufs_bounds_dev != c->ws[WS_LUFS]) {
@@ -1229,19 +1565,181 @@ int ss_kweighted_block_power_f32(const float* audio, int64_t T, int32_t C, const
         c->lufs_bounds.insert(c->lufs_bounds.end(), hi, hi + nblocks);
         c->lufs_bounds_dev = c->ws[WS_LUFS];
     }
+    // per-lane carry powers (M^KW_SER)^lane of the scan: uploaded when the coefficients change (i.e. once per sample rate)
+    const int ntiles = (nchunks + KW_TILE * KW_SER - 1) / (KW_TILE * KW_SER);
+    const size_t koff = (sizeof(KwCoef) + 255) & ~(size_t)255;      // ws[WS_KWP] = [KwCoef][72 4x4 carry-power matrices]
+    const size_t ptab_bytes = koff + sizeof(double) * (72 + 64) * 16;   // + [64] M^lane for the fused kernel
+    if ((rc = ws_ensure(c, WS_KWP, ptab_bytes))) return rc;                                       // fixed size: never reallocated
+    if ((rc = ws_ensure(c, WS_KWT, sizeof(double) * 4 * (size_t)C * ntiles))) return rc;           // tile totals
+    if (memcmp(c->kw_cached, k.b, sizeof(c->kw_cached)) != 0 || c->kw_cached_dev != c->ws[WS_KWP]) {
+        Pinned* pin;
+        if ((rc = pinned_acquire(c, ptab_bytes, &pin))) return rc;
+        memcpy(pin->host, &k, sizeof(KwCoef));
+        double* pt = (double*)((char*)pin->host + koff);
+        for (int i = 0; i < 16; ++i) pt[i] = (i % 5 == 0) ? 1.0 : 0.0;
+        for (int l = 1; l < 64; ++l)
+            for (int r = 0; r < 4; ++r)
+                for (int q = 0; q < 4; ++q) {
+                    double acc = 0;
+                    for (int m = 0; m < 4; ++m) acc += pt[(l - 1) * 16 + r * 4 + m] * k.Mp[3][m * 4 + q];
+                    pt[l * 16 + r * 4 + q] = acc;
+                }
+        double* qt = pt + 64 * 16;                      // (M^512)^wave
+        for (int i = 0; i < 16; ++i) qt[i] = (i % 5 == 0) ? 1.0 : 0.0;
+        for (int l = 1; l < 8; ++l)
+            for (int r = 0; r < 4; ++r)
+                for (int q = 0; q < 4; ++q) {
+                    double acc = 0;
+                    for (int m = 0; m < 4; ++m) acc += qt[(l - 1) * 16 + r * 4 + m] * k.Mp[9][m * 4 + q];
+                    qt[l * 16 + r * 4 + q] = acc;
+                }
+        double* lt = pt + 72 * 16;                      // M^lane
+        for (int i = 0; i < 16; ++i) lt[i] = (i % 5 == 0) ? 1.0 : 0.0;
+        for (int l = 1; l < 64; ++l)
+            for (int r = 0; r < 4; ++r)
+                for (int q = 0; q < 4; ++q) {
+                    double acc = 0;
+                    for (int m = 0; m < 4; ++m) acc += lt[(l - 1) * 16 + r * 4 + m] * k.Mp[0][m * 4 + q];
+                    lt[l * 16 + r * 4 + q] = acc;
+                }
+        HIPCHK(hipMemcpyAsync(c->ws[WS_KWP], pin->host, ptab_bytes, hipMemcpyHostToDevice, stream));
+        HIPCHK(hipEventRecord(pin->ev, stream));
+        pin->pending = true;
+        memcpy(c->kw_cached, k.b, sizeof(c->kw_cached));
+        c->kw_cached_dev = c->ws[WS_KWP];
+    }
     const int nthreads = C * nchunks;
     double* states = (double*)c->ws[WS_SCR];
     double* energy = (double*)c->ws[WS_FILT];
-    hipLaunchKernelGGL(k_kw_state, dim3((nthreads + 255) / 256), dim3(256), 0, stream, (const float*)da, T, C, st, sc, k, nchunks, states);
-    hipLaunchKernelGGL(k_kw_scan, dim3(C), dim3(256), 0, stream, k, nchunks, ngroups, gsz, states);
-    hipLaunchKernelGGL(k_kw_energy, dim3((nthreads + 255) / 256), dim3(256), 0, stream, (const float*)da, T, C, st, sc, k, nchunks,
-                       (const double*)states, energy);
-    hipLaunchKernelGGL(k_block_power_chunks, dim3(nblocks, C), dim3(64), 0, stream, (const float*)da, T, st, sc, k, nchunks,
+    const KwCoef* kd = (const KwCoef*)c->ws[WS_KWP];
+    double* ptab = (double*)((char*)c->ws[WS_KWP] + koff);
+    double* tot = (double*)c->ws[WS_KWT];
+    // history the fused kernel needs: the first power of two H with |M^H| <= 1e-20 entrywise
+    int hp = 0;
+    for (; hp < 10; ++hp) {
+        double mx = 0;
+        for (int i = 0; i < 16; ++i) mx = std::max(mx, std::fabs(k.Mp[hp][i]));
+        if (mx <= 1e-20) break;
+    }
+    const char* fe = getenv("SS_KW_EXACT");          // tests: force the exact multi-launch scan
+    const bool force_exact = fe && atoi(fe);
+    if (hp <= 8 && !force_exact) {
+        const int H = 1 << hp;
+        const double* plane = ptab + 72 * 16;
+        if (H <= 64) {
+            const int nt = 256, tiles = (nchunks + (nt - H) - 1) / (nt - H);
+            hipLaunchKernelGGL(k_kw_fused<256>, dim3(tiles, C), dim3(nt), 0, stream, da, T, st, sc, kd, plane, nchunks, H, states, energy);
+        } else {
+            const int nt = 512, tiles = (nchunks + (nt - H) - 1) / (nt - H);
+            hipLaunchKernelGGL(k_kw_fused<512>, dim3(tiles, C), dim3(nt), 0, stream, da, T, st, sc, kd, plane, nchunks, H, states, energy);
+        }
+    } else {
+        hipLaunchKernelGGL(k_kw_state, dim3((nthreads + 255) / 256), dim3(256), 0, stream, da, T, C, st, sc, kd, nchunks, states);
+        hipLaunchKernelGGL(k_kw_scan_local, dim3(ntiles, C), dim3(KW_TILE), 0, stream, kd, nchunks, ntiles, (const double*)ptab, states, tot);
+        if (ntiles > 1)
+            hipLaunchKernelGGL(k_kw_scan_carry, dim3(ntiles - 1, C), dim3(KW_TILE), 0, stream, kd, nchunks, ntiles, (const double*)ptab,
+                               states, (const double*)tot);
+        hipLaunchKernelGGL(k_kw_energy, dim3((nthreads + 255) / 256), dim3(256), 0, stream, da, T, C, st, sc, kd, nchunks,
+                           (const double*)states, energy);
+    }
+    hipLaunchKernelGGL(k_block_power_chunks, dim3(nblocks, C), dim3(64), 0, stream, da, T, st, sc, kd, nchunks,
                        (const double*)states, (const double*)energy, (const int64_t*)c->ws[WS_LUFS],
                        (const int64_t*)((const char*)c->ws[WS_LUFS] + bb), nblocks, 1.0 / norm, (double*)c->ws[WS_SCR2]);
     HIPCHK(hipGetLastError());
+    return SS_OK;
+}
+
+int ss_kweighted_block_power_f32(const float* audio, int64_t T, int32_t C, const double* coef, const int64_t* lo,
+                                 const int64_t* hi, int32_t nblocks, double norm, double* z_out, uint32_t flags, void* stream_) {
+    if (!audio || T <= 0 || C < 1 || C > 64 || !coef || nblocks < 0 || (nblocks && (!lo || !hi)) || !z_out || !(norm > 0))
+        return fail(SS_EINVAL, "bad argument");
+    if (nblocks == 0) return SS_OK;
+    std::lock_guard<std::mutex> lk(g_mu);
+    Ctx* c;
+    int rc = get_ctx(&c);
+    if (rc) return rc;
+    hipStream_t stream = (hipStream_t)stream_;
+    if ((rc = stream_enter(c, stream))) return rc;
+    const void* da;
+    if ((rc = stage_in(c, WS_Y, audio, sizeof(float) * (size_t)C * T, (flags & SS_FLAG_DEVICE_PTR) != 0, stream, &da))) return rc;
+    const bool tc = (flags & SS_FLAG_LAYOUT_TC) != 0;
+    KwCoef k;
+    if ((rc = kw_setup(coef, k))) return rc;
+    if ((rc = kw_block_power_dev(c, (const float*)da, T, C, tc ? C : 1, tc ? 1 : T, k, lo, hi, nblocks, norm, stream))) return rc;
     HIPCHK(hipMemcpyAsync(z_out, c->ws[WS_SCR2], sizeof(double) * (size_t)C * nblocks, hipMemcpyDeviceToHost, stream));
     HIPCHK(hipStreamSynchronize(stream));
+    return SS_OK;
+}
+
+int ss_lufs_norm_f32(const float* audio, float* out, int64_t T, int32_t C, const double* coef, const int64_t* lo, const int64_t* hi,
+                     int32_t nblocks, double block_norm, const double* weights, double target_lufs, double* result, uint32_t flags,
+                     void* stream_) {
+    if (!audio || !out || T <= 0 || C < 1 || C > 64 || !coef || nblocks < 0 || (nblocks && (!lo || !hi)) || !weights || !result ||
+        !(block_norm > 0))
+        return fail(SS_EINVAL, "bad argument");
+    std::lock_guard<std::mutex> lk(g_mu);
+    Ctx* c;
+    int rc = get_ctx(&c);
+    if (rc) return rc;
+    hipStream_t stream = (hipStream_t)stream_;
+    if ((rc = stream_enter(c, stream))) return rc;
+    const bool dev = (flags & SS_FLAG_DEVICE_PTR) != 0;
+    const int64_t n = (int64_t)C * T;
+    const void* da;
+    if ((rc = stage_in(c, WS_Y, audio, sizeof(float) * (size_t)n, dev, stream, &da))) return rc;
+    float* dout = out;
+    if (!dev) {
+        if ((rc = ws_ensure(c, WS_X, sizeof(float) * (size_t)n))) return rc;
+        dout = (float*)c->ws[WS_X];
+    }
+    const bool tc = (flags & SS_FLAG_LAYOUT_TC) != 0;
+    KwCoef k;
+    if ((rc = kw_setup(coef, k))) return rc;
+    const int nb = grid_for(n, 1024);
+    if ((rc = ws_ensure(c, WS_RES, sizeof(double) * (8 + 2 * (size_t)nb)))) return rc;   // [8] results, [2][nb] partial sums
+    double* res = (double*)c->ws[WS_RES];
+    if (nblocks) {
+        if ((rc = kw_block_power_dev(c, (const float*)da, T, C, tc ? C : 1, tc ? 1 : T, k, lo, hi, nblocks, block_norm, stream))) return rc;
+    } else if ((rc = ws_ensure(c, WS_SCR2, 64))) return rc;
+    if ((rc = ws_ensure(c, WS_GW, sizeof(double) * 64))) return rc;       // channel weights: uploaded when they change
+    {
+        double gw[64];
+        for (int i = 0; i < 64; ++i) gw[i] = i < C ? weights[i] : 0.0;
+        if (memcmp(c->gw_cached, gw, sizeof(gw)) != 0 || c->gw_cached_dev != c->ws[WS_GW]) {
+            Pinned* pin;
+            if ((rc = pinned_acquire(c, sizeof(gw), &pin))) return rc;
+            memcpy(pin->host, gw, sizeof(gw));
+            HIPCHK(hipMemcpyAsync(c->ws[WS_GW], pin->host, sizeof(gw), hipMemcpyHostToDevice, stream));
+            HIPCHK(hipEventRecord(pin->ev, stream));
+            pin->pending = true;
+            memcpy(c->gw_cached, gw, sizeof(gw));
+            c->gw_cached_dev = c->ws[WS_GW];
+        }
+    }
+    double* zdev = (double*)c->ws[WS_SCR2];
+    const size_t gate_lds = sizeof(double) * ((size_t)C + 1) * nblocks;
+    const int use_lds = gate_lds <= 60 * 1024;          // z and the block loudness in LDS when they fit the default dynamic limit
+    hipLaunchKernelGGL(k_gate, dim3(1), dim3(1024), use_lds ? gate_lds : 0, stream, (const double*)zdev, (int)C, (int)nblocks,
+                       (const double*)c->ws[WS_GW], target_lufs, zdev + (size_t)C * nblocks, use_lds, res);
+    double* part = res + 8;
+    hipLaunchKernelGGL(k_scale_sums, dim3(nb), dim3(256), 0, stream, (const float*)da, dout, n, 0.f, (const double*)(res + 1), part);
+    HIPCHK(hipGetLastError());
+    // {loudness, gain} + the 2 x nb partial sums come back in one go; the last (fixed-order) additions are done here
+    Pinned* pin;
+    if ((rc = pinned_acquire(c, sizeof(double) * (8 + 2 * (size_t)nb), &pin))) return rc;
+    double* hp_ = (double*)pin->host;
+    HIPCHK(hipMemcpyAsync(hp_, res, sizeof(double) * (8 + 2 * (size_t)nb), hipMemcpyDeviceToHost, stream));
+    if (!dev) HIPCHK(hipMemcpyAsync(out, dout, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    result[0] = hp_[0];
+    result[1] = hp_[1];
+    for (int h = 0; h < 2; ++h) {
+        double lanes[64] = {0};                         // same association as k_final_sum: 64 strided lanes, then a butterfly
+        for (int i = 0; i < nb; ++i) lanes[i & 63] += hp_[8 + (size_t)h * nb + i];
+        for (int o = 32; o > 0; o >>= 1)
+            for (int i = 0; i < o; ++i) lanes[i] += lanes[i + o];
+        result[2 + h] = lanes[0];
+    }
     return SS_OK;
 }
 
@@ -1269,7 +1767,7 @@ int ss_scale_f32(const float* in, float* out, int64_t n, float gain, double* sum
         if ((rc = ws_ensure(c, WS_SCR, sizeof(double) * (size_t)nb * 2))) return rc;
         if ((rc = ws_ensure(c, WS_SCR2, sizeof(double) * 2))) return rc;
         double* part = (double*)c->ws[WS_SCR];
-        hipLaunchKernelGGL(k_scale_sums, dim3(nb), dim3(256), 0, stream, (const float*)din, dout, n, gain, part);
+        hipLaunchKernelGGL(k_scale_sums, dim3(nb), dim3(256), 0, stream, (const float*)din, dout, n, gain, (const double*)nullptr, part);
         hipLaunchKernelGGL(k_final_sum, dim3(2), dim3(64), 0, stream, (const double*)part, nb, (double*)c->ws[WS_SCR2]);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(sums_out, c->ws[WS_SCR2], sizeof(double) * 2, hipMemcpyDeviceToHost, stream));
@@ -1282,6 +1780,13 @@ int ss_scale_f32(const float* in, float* out, int64_t n, float gain, double* sum
     return SS_OK;
 }
 
+#ifdef SS_DEBUG_CLK
+int ss_debug_clk(unsigned long long* out) {
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg_clk), sizeof(unsigned long long) * 8 * 2 * 256));
+    return SS_OK;
+}
+#endif
 int ss_prof_enable(int on) {
     std::lock_guard<std::mutex> lk(g_mu);
     Ctx* c;

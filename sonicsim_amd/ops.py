@@ -282,6 +282,41 @@ def kweighted_block_power(audio, coef, lo, hi, norm, layout_tc=True):
     return z
 
 
+def lufs_norm(audio, coef, lo, hi, block_norm, weights, target_lufs, layout_tc=True):
+    """Row U in one call (SonicSim_audio.py:68-81): block powers, BS.1770-4 gating, gain and scaling on the device.
+    Returns (out like audio, loudness, linear gain, sum(out), sum(audio))."""
+    lib = _lib.load()
+    coef = np.ascontiguousarray(np.asarray(coef, dtype=np.float64).reshape(2, 6))
+    lo = np.ascontiguousarray(np.asarray(lo, dtype=np.int64))
+    hi = np.ascontiguousarray(np.asarray(hi, dtype=np.int64))
+    nb = lo.shape[0]
+    flags = _lib.FLAG_LAYOUT_TC if layout_tc else 0
+    res = (ctypes.c_double * 4)()
+    dev = _is_dev(audio)
+    if dev:
+        import torch
+        a = _dev32(audio, "audio")
+        out = torch.empty_like(a)
+        _set_device(a)
+        flags |= _lib.FLAG_DEVICE_PTR
+        stream = _stream_ptr(a)
+    else:
+        a = _np32(audio, "audio")
+        out = np.empty_like(a)
+        stream = None
+    if a.ndim == 1:
+        T, C = a.shape[0], 1
+    else:
+        T, C = (a.shape[0], a.shape[1]) if layout_tc else (a.shape[1], a.shape[0])
+    w = np.ascontiguousarray(np.asarray(weights, dtype=np.float64)[:C])
+    if w.shape[0] != C:
+        raise ValueError("need one channel weight per channel")
+    _lib.check(lib.ss_lufs_norm_f32(_ptr(a), _ptr(out), T, C, coef.ctypes.data_as(_lib.c_f64p), lo.ctypes.data_as(_lib.c_i64p),
+                                    hi.ctypes.data_as(_lib.c_i64p), nb, float(block_norm), w.ctypes.data_as(_lib.c_f64p),
+                                    float(target_lufs), res, flags, stream))
+    return out, res[0], res[1], res[2], res[3]
+
+
 def scale(a, gain, want_sums=False):
     """out = gain * a (pyloudnorm.normalize.loudness); optional (sum(out), sum(a)) in float64."""
     lib = _lib.load()

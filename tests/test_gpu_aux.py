@@ -127,3 +127,38 @@ def test_lufs_matches_oracle(gpu):
     dev = torch.from_numpy(a8).to(gpu)
     assert abs(A.integrated_loudness(dev, 16000, allow_many_channels=True) - got) < 1e-9
     assert A.integrated_loudness(np.zeros((16000, 1), np.float32), 16000) == float("-inf")
+
+
+def test_lufs_scan_paths_and_edges(gpu, monkeypatch, capsys):
+    """Row U engines: the single-launch (history-truncated) K-weighting kernel and the exact multi-launch scan agree with the
+    oracle on multi-tile lengths, ragged tails, the channel-first device layout and silence (reference fallback -40)."""
+    from sonicsim_amd import SonicSim_audio as A
+    rng = np.random.default_rng(11)
+    for fs, T, C in ((16000, 16000 * 40 + 37, 2), (44100, 44100 * 7 + 5, 1), (8000, 3333, 3)):
+        env = np.repeat(rng.uniform(0.05, 1, size=T // 4000 + 1), 4000)[:T]
+        a = (rng.standard_normal((T, C)) * 0.1 * env[:, None]).astype(np.float32)
+        ref = OL.integrated_loudness(a, fs, block_size=0.4 if T / fs >= 0.4 else T / fs)
+        np.random.seed(5)
+        rn, rg = OL.get_lufs_norm_audio(a, fs, -20)
+        for exact in ("0", "1"):
+            monkeypatch.setenv("SS_KW_EXACT", exact)
+            got = A.integrated_loudness(a, fs, block_size=0.4 if T / fs >= 0.4 else T / fs)
+            assert abs(got - ref) < 1e-6, (fs, exact, got, ref)
+            np.random.seed(5)
+            gn, gg = A.get_lufs_norm_audio(a, fs, -20)
+            assert rel_rms(gn, rn) < 1e-6 and abs(gg - rg) < 1e-5 * abs(rg), (fs, exact)
+            # channel-first device tensor (the renderer's layout): same numbers, output stays on the device
+            d = torch.from_numpy(np.ascontiguousarray(a.T)).to(gpu)
+            np.random.seed(5)
+            dn, dg = A.get_lufs_norm_audio(d, fs, -20, channel_first=True)
+            assert dn.is_cuda and rel_rms(dn.cpu().numpy().T, rn) < 1e-6 and abs(dg - rg) < 1e-5 * abs(rg)
+    monkeypatch.delenv("SS_KW_EXACT")
+    z = np.zeros((16000, 1), np.float32)
+    z[100, 0] = 1e-30
+    np.random.seed(3)
+    rn, rg = OL.get_lufs_norm_audio(z, 16000, -17)
+    capsys.readouterr()
+    np.random.seed(3)
+    gn, gg = A.get_lufs_norm_audio(z, 16000, -17)
+    assert "loudness is inf" in capsys.readouterr().out
+    assert np.allclose(gn, rn, rtol=1e-6, atol=0) and abs(gg - rg) <= 1e-5 * abs(rg)
