@@ -115,7 +115,9 @@ def main():
             y = step()
         parallel.gather_to_root(y, dst=0)          # untimed: RCCL builds its point-to-point channels on first use
     torch.cuda.synchronize()
-    ops.prof_enable(not os.environ.get("BENCH_NOPROF"))        # BENCH_NOPROF=1: measure the event-free step time (diagnostics)
+    # HIP events bracket every 4th launch of the render kernel inside the timed region (an event pair is two barrier packets
+    # = a few us of launch gap per step); BENCH_PROF_EVERY=1 times every launch, BENCH_NOPROF=1 none (diagnostics)
+    ops.prof_enable(not os.environ.get("BENCH_NOPROF"), every=int(os.environ.get("BENCH_PROF_EVERY", "4")))
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -132,13 +134,14 @@ def main():
     dt = parallel.barrier_max_seconds(dt, device=dev)
     n_os, ms_os = ops.prof_read(0)
     n_xs, ms_xs = ops.prof_read(1)
+    n_os_all = ops.prof_seen(0)
     ops.prof_enable(False)
 
     if rank == 0:
         audio_s = sc.T / sc.fs
         value = world * args.steps * audio_s / dt
         render_bytes = algorithmic_bytes(sc.T, sc.P, sc.C, sc.L)
-        launches_per_render = n_os / max(1, args.steps)
+        launches_per_render = (n_os_all if n_os_all else n_os) / max(1, args.steps)
         avg_launch_ms = ms_os / max(1, n_os)
         bytes_per_launch = render_bytes / max(1.0, launches_per_render)
         achieved = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
@@ -175,7 +178,8 @@ def main():
                          "algorithmic_bytes_per_render": render_bytes, "launches_per_render": launches_per_render,
                          "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_ms": avg_launch_ms,
                          "xspec_avg_launch_ms": ms_xs / max(1, n_xs),
-                         "gpu_ms_per_render_kernels": (ms_os + ms_xs) / max(1, args.steps)},
+                         "timed_launches": n_os, "launches_in_timed_region": n_os_all,
+                         "gpu_ms_per_render_kernels": avg_launch_ms * launches_per_render + ms_xs / max(1, n_xs)},
         }
         if world == 1 and args.cpu_positions > 0:
             cb, yref, idx, w, bank_h = cpu_baseline(sc, seg, bank, args.cpu_positions)

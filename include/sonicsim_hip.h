@@ -140,10 +140,13 @@ int ss_lufs_norm_f32(const float* audio, float* out, int64_t T, int32_t C, const
 
 /* ---- measurement hooks (bench.py): HIP-event timing of the dominant kernels on their own stream.
  * kind 0 = overlap-save render kernel (one parity pass = one launch), 1 = input-spectra kernel,
- * 2 = direct-form kernel.  ss_prof_read synchronises, then returns count and total milliseconds
- * accumulated since the last ss_prof_enable(1). */
+ * 2 = direct-form kernel.  ss_prof_enable(0) = off, 1 = every launch, N > 1 = every N-th launch of each
+ * kind (an event pair costs two barrier packets).  ss_prof_read synchronises, then returns the number of
+ * timed launches and their total milliseconds accumulated since the last ss_prof_enable(on != 0). */
 int ss_prof_enable(int on);
 int ss_prof_read(int kind, int64_t* launches, double* total_ms);
+/* all launches of `kind` since ss_prof_enable(on != 0), timed or not */
+int ss_prof_seen(int kind, int64_t* launches);
 
 #ifdef __cplusplus
 }

@@ -62,6 +62,7 @@ _SIGS = {
                                         ctypes.c_void_p]),
     "ss_prof_enable": (ctypes.c_int, [ctypes.c_int]),
     "ss_prof_read": (ctypes.c_int, [ctypes.c_int, c_i64p, c_f64p]),
+    "ss_prof_seen": (ctypes.c_int, [ctypes.c_int, c_i64p]),
 }
 
 EXPORTS = tuple(_SIGS)

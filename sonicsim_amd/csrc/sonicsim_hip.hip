@@ -844,6 +844,8 @@ struct Ctx {
     bool have_last = false;
     bool prof = false;
     std::vector<EvPair> evs;
+    int prof_every = 1;                    // ss_prof_enable(N > 1): time every N-th launch of each kind only
+    unsigned prof_seen[4] = {0, 0, 0, 0};
     std::vector<hipEvent_t> ev_pool;      // recycled timing events (creating events costs host time inside the timed loop)
     int os_variant = 3;     // SS_OS_VARIANT: prefetch depth of the render kernel (0, 2, 3) -- tuning knob
     int os_ablate = 0;      // SS_OS_ABLATE: profiling-only ablation mask (results are WRONG when != 0)
@@ -954,6 +956,7 @@ struct ProfScope {
     bool on;
     EvPair ev;
     ProfScope(Ctx* c_, hipStream_t s_, int kind_) : c(c_), s(s_), kind(kind_), on(c_->prof) {
+        if (on && (c->prof_seen[kind_ & 3]++ % c->prof_every) != 0) on = false;   // sampled: every N-th launch
         if (on) {
             ev.kind = kind;
             auto get = [&](hipEvent_t* e) {
@@ -1798,6 +1801,18 @@ int ss_prof_enable(int on) {
     if (on && c->ev_pool.size() < 256)
         for (int i = 0; i < 256; ++i) { hipEvent_t e; if (hipEventCreate(&e) == hipSuccess) c->ev_pool.push_back(e); }
     c->prof = on != 0;
+    c->prof_every = on > 1 ? on : 1;
+    memset(c->prof_seen, 0, sizeof(c->prof_seen));
+    return SS_OK;
+}
+
+int ss_prof_seen(int kind, int64_t* launches) {
+    if (!launches || kind < 0 || kind > 3) return fail(SS_EINVAL, "bad argument");
+    std::lock_guard<std::mutex> lk(g_mu);
+    Ctx* c;
+    int rc = get_ctx(&c);
+    if (rc) return rc;
+    *launches = c->prof_seen[kind];
     return SS_OK;
 }
 

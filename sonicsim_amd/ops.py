@@ -335,8 +335,17 @@ def scale(a, gain, want_sums=False):
     return (out, (sums[0], sums[1])) if want_sums else out
 
 
-def prof_enable(on=True):
-    _lib.check(_lib.load().ss_prof_enable(1 if on else 0))
+def prof_enable(on=True, every=1):
+    """HIP-event timing of the dominant kernels; every=N > 1 brackets only every N-th launch of each kind (an event pair
+    costs two barrier packets, i.e. a few microseconds of launch gap)."""
+    _lib.check(_lib.load().ss_prof_enable((max(1, int(every)) if on else 0)))
+
+
+def prof_seen(kind=0):
+    """All launches of `kind` since prof_enable(True), timed or not."""
+    n = ctypes.c_int64(0)
+    _lib.check(_lib.load().ss_prof_seen(int(kind), ctypes.byref(n)))
+    return int(n.value)
 
 
 def prof_read(kind=0):
