@@ -1,0 +1,25 @@
+"""GPU box: per-workgroup (start, end) wall-clock stamps of one k_os13_asm launch (code object built with OS13_OPT=wgclk).
+usage: SS_HSACO=sonicsim_amd/lib/var_wgclk.hsaco SS_TRACE_FILE=gpurun_out/wgclk.bin python tools/wgclk.py"""
+import os, sys, numpy as np, torch
+sys.path.insert(0, ".")
+from sonicsim_amd import ops, synth
+ops.init(0)
+dev = torch.device("cuda:0")
+sc = synth.make_scene("cfg2", scene=0)
+seg = synth.scene_segments(sc, 0)
+bank = ops.rir_bank_synth(sc.delay, sc.dgain, sc.L, sc.fs, sc.rt60, sc.bank_seed, device=dev)
+ops.peak_normalize_(bank)
+x = torch.from_numpy(sc.x).to(dev)
+for _ in range(4):
+    y = ops.convolve_moving_seg(x, bank, seg)
+torch.cuda.synchronize()
+raw = np.fromfile(os.environ["SS_TRACE_FILE"], dtype=np.uint64)[:512].reshape(256, 2).astype(np.int64)
+st, en = raw[:, 0], raw[:, 1]
+ok = st > 0
+st, en = st[ok], en[ok]
+t0 = st.min()
+us = lambda v: v / 100.0
+print("workgroups", ok.sum(), " span us %.1f" % us(en.max() - t0))
+print("start: median +%.1f  p90 +%.1f  max +%.1f us" % (us(np.median(st) - t0), us(np.percentile(st, 90) - t0), us(st.max() - t0)))
+print("end  : min %.1f  p10 %.1f  median %.1f  p90 %.1f  max %.1f us" % tuple(us(v - t0) for v in (en.min(), np.percentile(en, 10), np.median(en), np.percentile(en, 90), en.max())))
+print("busy per workgroup us: min %.1f median %.1f max %.1f" % (us((en - st).min()), us(np.median(en - st)), us((en - st).max())))
