@@ -138,6 +138,14 @@ int ss_lufs_norm_f32(const float* audio, float* out, int64_t T, int32_t C, const
                      const double* weights, double target_lufs, double* result, uint32_t flags,
                      void* stream);
 
+/* The same for S stems in one call (one launch sequence, one synchronisation): audio/out are [S][C][T]
+ * channel-first contiguous, targets[S] (HOST) the drawn class loudness of every stem, result[S][4] as above.
+ * S <= 16 and S * C <= 64. */
+int ss_lufs_norm_batch_f32(const float* audio, float* out, int64_t T, int32_t C, int32_t S,
+                           const double* coef, const int64_t* lo, const int64_t* hi, int32_t nblocks,
+                           double block_norm, const double* weights, const double* targets,
+                           double* result, uint32_t flags, void* stream);
+
 /* ---- measurement hooks (bench.py): HIP-event timing of the dominant kernels on their own stream.
  * kind 0 = overlap-save render kernel (one parity pass = one launch), 1 = input-spectra kernel,
  * 2 = direct-form kernel.  ss_prof_enable(0) = off, 1 = every launch, N > 1 = every N-th launch of each

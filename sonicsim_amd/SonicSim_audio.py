@@ -178,6 +178,23 @@ def lufs_norm(data, sr, norm=-6, allow_many_channels: bool = False, channel_firs
     return norm_data, gain
 
 
+def get_lufs_norm_audio_batch(stems, sr=16000, lufs=(-6,), allow_many_channels: bool = False):
+    """Extension: ``get_lufs_norm_audio`` for a stack of stems (S, C, T) in ONE device call.  The class loudness of stem i
+    is drawn from the global NumPy RNG in stem order, exactly as S successive reference calls (:83-86) would draw them.
+    Returns (normalised stack (S, C, T), [gain_0, ...])."""
+    S, C, T = stems.shape
+    if len(lufs) != S:
+        raise ValueError("one nominal loudness per stem")
+    targets = [np.random.uniform(l - 2, l + 2) for l in lufs]
+    block_size = 0.4 if T / sr >= 0.4 else T / sr
+    _, lo, hi, weights, _ = _meter_args(stems[0], sr, block_size, allow_many_channels, True)
+    out, loud, _lin, n, d = ops.lufs_norm(stems, _kw_coef(float(sr)), lo, hi, block_size * sr, weights, targets, layout_tc=False)
+    for l in loud:
+        if math.isinf(l):
+            print("loudness is inf")
+    return out, [ni / di if di else 0.0 for ni, di in zip(n, d)]
+
+
 def get_lufs_norm_audio(audio, sr=16000, lufs=-6, allow_many_channels: bool = False, channel_first: bool = False):
     """SonicSim_audio.py:83-86: target drawn from the GLOBAL NumPy RNG, U(lufs-2, lufs+2)."""
     class_lufs = np.random.uniform(lufs - 2, lufs + 2)

@@ -60,6 +60,9 @@ _SIGS = {
     "ss_lufs_norm_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, c_f64p, c_i64p, c_i64p,
                                         ctypes.c_int32, ctypes.c_double, c_f64p, ctypes.c_double, c_f64p, ctypes.c_uint32,
                                         ctypes.c_void_p]),
+    "ss_lufs_norm_batch_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, c_f64p,
+                                              c_i64p, c_i64p, ctypes.c_int32, ctypes.c_double, c_f64p, c_f64p, c_f64p, ctypes.c_uint32,
+                                              ctypes.c_void_p]),
     "ss_prof_enable": (ctypes.c_int, [ctypes.c_int]),
     "ss_prof_read": (ctypes.c_int, [ctypes.c_int, c_i64p, c_f64p]),
     "ss_prof_seen": (ctypes.c_int, [ctypes.c_int, c_i64p]),

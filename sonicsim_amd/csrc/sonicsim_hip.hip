@@ -227,10 +227,15 @@ __global__ __launch_bounds__(64) void k_final_sum(const double* __restrict__ par
 }
 // out = gain * in with the float64 partial sums of out and in in the same pass (pyloudnorm.normalize.loudness + :78-79).
 // gain_dev != nullptr: the gain is the float64 the gating kernel left on the device (rounded to float32 like the host path).
+// blockIdx.y = group (stem): its n elements start at group * n, its gain is gain_dev[4 * group], its partial sums go to
+// partial[(2 * group + {0,1}) * gridDim.x + blockIdx.x].
 __global__ __launch_bounds__(256) void k_scale_sums(const float* __restrict__ in, float* __restrict__ out, int64_t n, float gain,
-                                                    const double* __restrict__ gain_dev, double* __restrict__ partial /*[2][grid]*/) {
+                                                    const double* __restrict__ gain_dev, double* __restrict__ partial /*[groups][2][grid]*/) {
     __shared__ double sw[2][4];
-    if (gain_dev) gain = (float)*gain_dev;
+    if (gain_dev) gain = (float)gain_dev[4 * blockIdx.y];
+    in += (int64_t)blockIdx.y * n;
+    out += (int64_t)blockIdx.y * n;
+    partial += (int64_t)2 * blockIdx.y * gridDim.x;
     double so = 0.0, si = 0.0;
     const int64_t stride = (int64_t)gridDim.x * 256, tid = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if ((((uintptr_t)in | (uintptr_t)out) & 15) == 0) {
@@ -732,8 +737,14 @@ __global__ __launch_bounds__(64) void k_block_power_chunks(const float* __restri
 // BS.1770-4 two-stage gating (pyloudnorm.Meter.integrated_loudness) over z[C][nblocks], then the gain of lufs_norm
 // (SonicSim_audio.py:68-77): res[0] = integrated loudness (-inf when no block survives), res[1] = 10^((target - L)/20) with
 // L := -40 when the loudness is -inf (the reference's fallback).  One workgroup; wave w reduces channels w, w+4, ...
-__global__ __launch_bounds__(1024) void k_gate(const double* __restrict__ z, int C, int nblocks, const double* __restrict__ gw /*[C] channel weights*/, double target,
+struct GateTargets { double t[16]; };   // drawn class loudness per stem
+__global__ __launch_bounds__(1024) void k_gate(const double* __restrict__ z, int C, int nblocks, const double* __restrict__ gw /*[C] channel weights*/, GateTargets targets,
                                                double* __restrict__ lbuf /*[nblocks] scratch*/, int use_lds, double* __restrict__ res) {
+    // blockIdx.x = group (stem) of C channels: its own z rows, scratch, target and result slot
+    z += (int64_t)blockIdx.x * C * nblocks;
+    lbuf += (int64_t)blockIdx.x * nblocks;
+    res += 4 * blockIdx.x;
+    const double target = targets.t[blockIdx.x];
     DBG_CLK(2, 0);
     extern __shared__ double gsm[];                      // use_lds: [C][nblocks] copy of z, then [nblocks] block loudness
     __shared__ double part[65];                          // [channel] sums over the kept blocks, [64] = kept-block count
@@ -1553,7 +1564,7 @@ static int kw_block_power_dev(Ctx* c, const float* da, int64_t T, int32_t C, int
     if ((rc = ws_ensure(c, WS_FILT, sizeof(double) * (size_t)C * nchunks))) return rc;          // chunk energies
     const size_t bb = sizeof(int64_t) * (size_t)nblocks;
     if ((rc = ws_ensure(c, WS_LUFS, 2 * bb))) return rc;
-    if ((rc = ws_ensure(c, WS_SCR2, sizeof(double) * ((size_t)C + 1) * nblocks))) return rc;   // z + the gate's per-block scratch
+    if ((rc = ws_ensure(c, WS_SCR2, sizeof(double) * ((size_t)C + 16) * nblocks))) return rc;   // z + the gate's per-block scratch (one row per stem)
     // block bounds: uploaded only when they differ from the previous call's (same T / rate / block size -> same bounds)
     if (c->lufs_bounds.size() != 2 * (size_t)nblocks || memcmp(c->lufs_bounds.data(), lo, bb) != 0 ||
         memcmp(c->lufs_bounds.data() + nblocks, hi, bb) != 0 || c->lufs_bounds_dev != c->ws[WS_LUFS]) {
@@ -1674,12 +1685,14 @@ int ss_kweighted_block_power_f32(const float* audio, int64_t T, int32_t C, const
     return SS_OK;
 }
 
-int ss_lufs_norm_f32(const float* audio, float* out, int64_t T, int32_t C, const double* coef, const int64_t* lo, const int64_t* hi,
-                     int32_t nblocks, double block_norm, const double* weights, double target_lufs, double* result, uint32_t flags,
-                     void* stream_) {
-    if (!audio || !out || T <= 0 || C < 1 || C > 64 || !coef || nblocks < 0 || (nblocks && (!lo || !hi)) || !weights || !result ||
-        !(block_norm > 0))
+int ss_lufs_norm_batch_f32(const float* audio, float* out, int64_t T, int32_t C, int32_t S, const double* coef, const int64_t* lo,
+                           const int64_t* hi, int32_t nblocks, double block_norm, const double* weights, const double* targets,
+                           double* result, uint32_t flags, void* stream_) {
+    if (!audio || !out || T <= 0 || C < 1 || S < 1 || S > 16 || (int64_t)C * S > 64 || !coef || nblocks < 0 || (nblocks && (!lo || !hi)) ||
+        !weights || !targets || !result || !(block_norm > 0))
         return fail(SS_EINVAL, "bad argument");
+    const bool tc = (flags & SS_FLAG_LAYOUT_TC) != 0;
+    if (tc && S > 1) return fail(SS_EINVAL, "a batch of stems must be channel-first [S][C][T]");
     std::lock_guard<std::mutex> lk(g_mu);
     Ctx* c;
     int rc = get_ctx(&c);
@@ -1687,7 +1700,8 @@ int ss_lufs_norm_f32(const float* audio, float* out, int64_t T, int32_t C, const
     hipStream_t stream = (hipStream_t)stream_;
     if ((rc = stream_enter(c, stream))) return rc;
     const bool dev = (flags & SS_FLAG_DEVICE_PTR) != 0;
-    const int64_t n = (int64_t)C * T;
+    const int64_t ng = (int64_t)C * T, n = ng * S;                 // elements per stem / in total
+    const int CC = C * S;                                          // [S][C][T] is a [S*C][T] signal for the K-weighting kernels
     const void* da;
     if ((rc = stage_in(c, WS_Y, audio, sizeof(float) * (size_t)n, dev, stream, &da))) return rc;
     float* dout = out;
@@ -1695,14 +1709,14 @@ int ss_lufs_norm_f32(const float* audio, float* out, int64_t T, int32_t C, const
         if ((rc = ws_ensure(c, WS_X, sizeof(float) * (size_t)n))) return rc;
         dout = (float*)c->ws[WS_X];
     }
-    const bool tc = (flags & SS_FLAG_LAYOUT_TC) != 0;
     KwCoef k;
     if ((rc = kw_setup(coef, k))) return rc;
-    const int nb = grid_for(n, 1024);
-    if ((rc = ws_ensure(c, WS_RES, sizeof(double) * (8 + 2 * (size_t)nb)))) return rc;   // [8] results, [2][nb] partial sums
+    const int nb = grid_for(ng, 1024);
+    const size_t res_doubles = 4 * (size_t)S + 2 * (size_t)S * nb;  // [S][4] results, [S][2][nb] partial sums
+    if ((rc = ws_ensure(c, WS_RES, sizeof(double) * res_doubles))) return rc;
     double* res = (double*)c->ws[WS_RES];
     if (nblocks) {
-        if ((rc = kw_block_power_dev(c, (const float*)da, T, C, tc ? C : 1, tc ? 1 : T, k, lo, hi, nblocks, block_norm, stream))) return rc;
+        if ((rc = kw_block_power_dev(c, (const float*)da, T, CC, tc ? C : 1, tc ? 1 : T, k, lo, hi, nblocks, block_norm, stream))) return rc;
     } else if ((rc = ws_ensure(c, WS_SCR2, 64))) return rc;
     if ((rc = ws_ensure(c, WS_GW, sizeof(double) * 64))) return rc;       // channel weights: uploaded when they change
     {
@@ -1722,28 +1736,39 @@ int ss_lufs_norm_f32(const float* audio, float* out, int64_t T, int32_t C, const
     double* zdev = (double*)c->ws[WS_SCR2];
     const size_t gate_lds = sizeof(double) * ((size_t)C + 1) * nblocks;
     const int use_lds = gate_lds <= 60 * 1024;          // z and the block loudness in LDS when they fit the default dynamic limit
-    hipLaunchKernelGGL(k_gate, dim3(1), dim3(1024), use_lds ? gate_lds : 0, stream, (const double*)zdev, (int)C, (int)nblocks,
-                       (const double*)c->ws[WS_GW], target_lufs, zdev + (size_t)C * nblocks, use_lds, res);
-    double* part = res + 8;
-    hipLaunchKernelGGL(k_scale_sums, dim3(nb), dim3(256), 0, stream, (const float*)da, dout, n, 0.f, (const double*)(res + 1), part);
+    GateTargets gt;
+    for (int i = 0; i < 16; ++i) gt.t[i] = i < S ? targets[i] : 0.0;
+    hipLaunchKernelGGL(k_gate, dim3(S), dim3(1024), use_lds ? gate_lds : 0, stream, (const double*)zdev, (int)C, (int)nblocks,
+                       (const double*)c->ws[WS_GW], gt, zdev + (size_t)CC * nblocks, use_lds, res);
+    double* part = res + 4 * (size_t)S;
+    hipLaunchKernelGGL(k_scale_sums, dim3(nb, S), dim3(256), 0, stream, (const float*)da, dout, ng, 0.f, (const double*)(res + 1), part);
     HIPCHK(hipGetLastError());
-    // {loudness, gain} + the 2 x nb partial sums come back in one go; the last (fixed-order) additions are done here
+    // {loudness, gain} + the partial sums of every stem come back in one go; the last (fixed-order) additions are done here
     Pinned* pin;
-    if ((rc = pinned_acquire(c, sizeof(double) * (8 + 2 * (size_t)nb), &pin))) return rc;
+    if ((rc = pinned_acquire(c, sizeof(double) * res_doubles, &pin))) return rc;
     double* hp_ = (double*)pin->host;
-    HIPCHK(hipMemcpyAsync(hp_, res, sizeof(double) * (8 + 2 * (size_t)nb), hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipMemcpyAsync(hp_, res, sizeof(double) * res_doubles, hipMemcpyDeviceToHost, stream));
     if (!dev) HIPCHK(hipMemcpyAsync(out, dout, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, stream));
     HIPCHK(hipStreamSynchronize(stream));
-    result[0] = hp_[0];
-    result[1] = hp_[1];
-    for (int h = 0; h < 2; ++h) {
-        double lanes[64] = {0};                         // same association as k_final_sum: 64 strided lanes, then a butterfly
-        for (int i = 0; i < nb; ++i) lanes[i & 63] += hp_[8 + (size_t)h * nb + i];
-        for (int o = 32; o > 0; o >>= 1)
-            for (int i = 0; i < o; ++i) lanes[i] += lanes[i + o];
-        result[2 + h] = lanes[0];
+    for (int g = 0; g < S; ++g) {
+        result[4 * g + 0] = hp_[4 * g + 0];
+        result[4 * g + 1] = hp_[4 * g + 1];
+        for (int h = 0; h < 2; ++h) {
+            const double* pp = hp_ + 4 * (size_t)S + ((size_t)2 * g + h) * nb;
+            double lanes[64] = {0};                     // same association as k_final_sum: 64 strided lanes, then a butterfly
+            for (int i = 0; i < nb; ++i) lanes[i & 63] += pp[i];
+            for (int o = 32; o > 0; o >>= 1)
+                for (int i = 0; i < o; ++i) lanes[i] += lanes[i + o];
+            result[4 * g + 2 + h] = lanes[0];
+        }
     }
     return SS_OK;
+}
+
+int ss_lufs_norm_f32(const float* audio, float* out, int64_t T, int32_t C, const double* coef, const int64_t* lo, const int64_t* hi,
+                     int32_t nblocks, double block_norm, const double* weights, double target_lufs, double* result, uint32_t flags,
+                     void* stream_) {
+    return ss_lufs_norm_batch_f32(audio, out, T, C, 1, coef, lo, hi, nblocks, block_norm, weights, &target_lufs, result, flags, stream_);
 }
 
 int ss_scale_f32(const float* in, float* out, int64_t n, float gain, double* sums_out, uint32_t flags, void* stream_) {

@@ -63,6 +63,16 @@ def init(device: int = -1):
     _lib.check(_lib.load().ss_init(int(device)))
 
 
+def _out_ct(out, C, T, dev):
+    """Device output (C, T): a fresh tensor, or the caller's contiguous float32 view (e.g. one slot of a stem stack)."""
+    import torch
+    if out is None:
+        return torch.empty((C, T), dtype=torch.float32, device=dev)
+    if not (_is_dev(out) and out.dtype == torch.float32 and tuple(out.shape) == (C, T) and out.is_contiguous() and out.device == dev):
+        raise ValueError("out must be a contiguous float32 device tensor of shape (C, T)")
+    return out
+
+
 def convolve_moving(x, rirs, idx, w, path=None):
     """Row V (SonicSim_moving.py:63-96).  x (T,), rirs (P,C,L), idx (T,) int, w (T,) -> (C,T)."""
     lib = _lib.load()
@@ -105,7 +115,7 @@ def _check_moving_shapes(x, rirs, idx, w):
         raise ValueError("interp_index / interp_weight must have shape (audio_len,)")
 
 
-def convolve_moving_seg(x, rirs, seg_len, path=None):
+def convolve_moving_seg(x, rirs, seg_len, path=None, out=None):
     """Rows I+V fused (SonicSim_moving.py:42-45 + :63-96): seg_len (P-1,) host ints, sum == T."""
     lib = _lib.load()
     flags = PATHS[path]
@@ -120,7 +130,7 @@ def convolve_moving_seg(x, rirs, seg_len, path=None):
         P, C, L = rirs.shape
         T = x.shape[0]
         _set_device(x)
-        y = torch.empty((C, T), dtype=torch.float32, device=dev)
+        y = _out_ct(out, C, T, dev)
         _lib.check(lib.ss_convolve_moving_seg_f32(_ptr(x), T, _ptr(rirs), P, C, L, _ptr(seg), _ptr(y),
                                                   flags | _lib.FLAG_DEVICE_PTR, _stream_ptr(x)))
         return y
@@ -135,7 +145,7 @@ def convolve_moving_seg(x, rirs, seg_len, path=None):
     return y
 
 
-def convolve_fixed(x, h, path=None):
+def convolve_fixed(x, h, path=None, out=None):
     """Row F (SonicSim_moving.py:47-61).  x (T,) or (1,T); h (C,L) -> (C,T)."""
     lib = _lib.load()
     flags = PATHS[path]
@@ -149,7 +159,7 @@ def convolve_fixed(x, h, path=None):
         C, L = h.shape
         T = x.shape[0]
         _set_device(x)
-        y = torch.empty((C, T), dtype=torch.float32, device=dev)
+        y = _out_ct(out, C, T, dev)
         _lib.check(lib.ss_convolve_fixed_f32(_ptr(x), T, _ptr(h), C, L, _ptr(y), flags | _lib.FLAG_DEVICE_PTR, _stream_ptr(x)))
         return y
     x = _np32(x, "x").reshape(-1)
@@ -284,14 +294,14 @@ def kweighted_block_power(audio, coef, lo, hi, norm, layout_tc=True):
 
 def lufs_norm(audio, coef, lo, hi, block_norm, weights, target_lufs, layout_tc=True):
     """Row U in one call (SonicSim_audio.py:68-81): block powers, BS.1770-4 gating, gain and scaling on the device.
-    Returns (out like audio, loudness, linear gain, sum(out), sum(audio))."""
+    audio (T,), (T,C) / (C,T), or a batch of stems (S,C,T) (channel-first only) with one target per stem.
+    Returns (out like audio, loudness, linear gain, sum(out), sum(audio)) -- scalars, or length-S lists for a batch."""
     lib = _lib.load()
     coef = np.ascontiguousarray(np.asarray(coef, dtype=np.float64).reshape(2, 6))
     lo = np.ascontiguousarray(np.asarray(lo, dtype=np.int64))
     hi = np.ascontiguousarray(np.asarray(hi, dtype=np.int64))
     nb = lo.shape[0]
     flags = _lib.FLAG_LAYOUT_TC if layout_tc else 0
-    res = (ctypes.c_double * 4)()
     dev = _is_dev(audio)
     if dev:
         import torch
@@ -304,17 +314,30 @@ def lufs_norm(audio, coef, lo, hi, block_norm, weights, target_lufs, layout_tc=T
         a = _np32(audio, "audio")
         out = np.empty_like(a)
         stream = None
-    if a.ndim == 1:
-        T, C = a.shape[0], 1
+    batch = a.ndim == 3
+    if batch:
+        if layout_tc:
+            raise ValueError("a batch of stems must be channel-first (S, C, T)")
+        S, C, T = a.shape
+    elif a.ndim == 1:
+        S, T, C = 1, a.shape[0], 1
     else:
+        S = 1
         T, C = (a.shape[0], a.shape[1]) if layout_tc else (a.shape[1], a.shape[0])
     w = np.ascontiguousarray(np.asarray(weights, dtype=np.float64)[:C])
     if w.shape[0] != C:
         raise ValueError("need one channel weight per channel")
-    _lib.check(lib.ss_lufs_norm_f32(_ptr(a), _ptr(out), T, C, coef.ctypes.data_as(_lib.c_f64p), lo.ctypes.data_as(_lib.c_i64p),
-                                    hi.ctypes.data_as(_lib.c_i64p), nb, float(block_norm), w.ctypes.data_as(_lib.c_f64p),
-                                    float(target_lufs), res, flags, stream))
-    return out, res[0], res[1], res[2], res[3]
+    tg = np.ascontiguousarray(np.asarray(target_lufs, dtype=np.float64).reshape(-1))
+    if tg.shape[0] != S:
+        raise ValueError("need one target loudness per stem")
+    res = (ctypes.c_double * (4 * S))()
+    _lib.check(lib.ss_lufs_norm_batch_f32(_ptr(a), _ptr(out), T, C, S, coef.ctypes.data_as(_lib.c_f64p), lo.ctypes.data_as(_lib.c_i64p),
+                                          hi.ctypes.data_as(_lib.c_i64p), nb, float(block_norm), w.ctypes.data_as(_lib.c_f64p),
+                                          tg.ctypes.data_as(_lib.c_f64p), res, flags, stream))
+    if not batch:
+        return out, res[0], res[1], res[2], res[3]
+    r = np.array(res[:], dtype=np.float64).reshape(S, 4)
+    return out, list(r[:, 0]), list(r[:, 1]), list(r[:, 2]), list(r[:, 3])
 
 
 def scale(a, gain, want_sums=False):

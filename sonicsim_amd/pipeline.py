@@ -51,15 +51,22 @@ def render_sonicset_sample(inp: SceneInputs, sirs=(0.0,), snr=15.0, lufs_seed=No
     """Returns (mix (C,T), stems [5 x (C,T)], gains) -- all torch tensors on the device."""
     if lufs_seed is not None:
         np.random.seed(lufs_seed)
-    stems = [ops.convolve_moving_seg(x, bank, seg) for (x, bank, seg) in inp.speakers]       # rows I+V
-    stems += [ops.convolve_fixed(x, h) for (x, h) in inp.statics]                             # row F
-    normed, gains = [], []
-    for y, target in zip(stems, LUFS_TARGETS):                                                # row U
-        n, g = A.get_lufs_norm_audio(y, inp.fs, target, allow_many_channels=True, channel_first=True)   # (C,T) in place of the reference's transposed (T,C)
-        normed.append(n)
-        gains.append(g)
     import torch
-    spk = torch.stack(normed[:2])                                                             # 2-speaker separation mixture
+    x0, bank0, _ = inp.speakers[0]
+    nstem = len(inp.speakers) + len(inp.statics)
+    stack = torch.empty((nstem, bank0.shape[1], x0.shape[-1]), dtype=torch.float32, device=x0.device)   # renders land in one stack
+    i = 0
+    for (x, bank, seg) in inp.speakers:                                                        # rows I+V
+        ops.convolve_moving_seg(x, bank, seg, out=stack[i])
+        i += 1
+    for (x, h) in inp.statics:                                                                 # row F
+        ops.convolve_fixed(x, h, out=stack[i])
+        i += 1
+    # row U for all stems in one device call (targets drawn in stem order like successive reference calls);
+    # (C,T) stems in place of the reference's transposed (T,C)
+    nstack, gains = A.get_lufs_norm_audio_batch(stack, inp.fs, LUFS_TARGETS[:nstem], allow_many_channels=True)
+    normed = [nstack[j] for j in range(nstem)]
+    spk = nstack[:2].clone()                                                     # 2-speaker separation mixture (the mix scales interferers in place, :113)
     noise = normed[3][None]
     mix, _ = mixing.mix_sources(spk, noise, np.asarray(sirs, dtype=np.float32), float(snr))   # row M
     return mix, normed, gains

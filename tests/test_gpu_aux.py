@@ -162,3 +162,31 @@ def test_lufs_scan_paths_and_edges(gpu, monkeypatch, capsys):
     gn, gg = A.get_lufs_norm_audio(z, 16000, -17)
     assert "loudness is inf" in capsys.readouterr().out
     assert np.allclose(gn, rn, rtol=1e-6, atol=0) and abs(gg - rg) <= 1e-5 * abs(rg)
+
+
+def test_lufs_batch_equals_single_calls(gpu):
+    """Row U for a stack of stems in one device call == successive single-stem calls (same RNG draws, same bits)."""
+    from sonicsim_amd import SonicSim_audio as A
+    rng = np.random.default_rng(12)
+    S, C, T = 5, 8, 16000 * 6 + 123
+    env = np.repeat(rng.uniform(0.05, 1, size=T // 4000 + 1), 4000)[:T]
+    stack = torch.from_numpy((rng.standard_normal((S, C, T)) * 0.1 * env * np.linspace(0.2, 2.0, S)[:, None, None]).astype(np.float32)).to(gpu)
+    stack[3] = 0.0                                            # a silent stem: -inf -> -40 fallback inside the batch
+    targets = (-17, -17, -17, -24, -29)
+    np.random.seed(21)
+    singles = [A.get_lufs_norm_audio(stack[i], 16000, targets[i], allow_many_channels=True, channel_first=True) for i in range(S)]
+    np.random.seed(21)
+    bn, bg = A.get_lufs_norm_audio_batch(stack, 16000, targets, allow_many_channels=True)
+    for i in range(S):
+        assert torch.equal(bn[i], singles[i][0]), i
+        assert bg[i] == singles[i][1], i
+    # and against the oracle, stem by stem
+    np.random.seed(21)
+    for i in (0, 4):
+        rn, rg = OL.get_lufs_norm_audio(stack[i].cpu().numpy().T, 16000, targets[i], allow_many_channels=True)
+        if i == 4:
+            assert rel_rms(bn[i].cpu().numpy().T, rn) < 1e-6 and abs(bg[i] - rg) < 1e-5 * abs(rg)
+        for _ in range(3 if i == 0 else 0):
+            np.random.uniform(0, 1)                           # skip the draws of stems 1..3
+    with pytest.raises(ValueError):
+        A.get_lufs_norm_audio_batch(stack, 16000, (-17,), allow_many_channels=True)
