@@ -119,8 +119,12 @@ inline void merge_lpt(Plan& plan, int NP, std::vector<Task>& out) {
 // :89-94), i.e. for a run of consecutive output blocks, cut into tasks of at most `jmax` blocks.  Tasks come out in descending
 // cost order (the persistent workgroups take them round-robin = LPT), row-major inside a cost class (neighbouring rows share
 // their input-spectra window in L2).  No per-call allocation once `out` / `scratch` have grown.
+// groups > 1 (XCD-aware order for persistent kernels whose workgroup b runs on XCD b % groups and takes tasks b, b + nwg, ...):
+// the rows are cut into `groups` contiguous time ranges of equal total cost, every range is sorted by descending cost on its
+// own, and the ranges are interleaved task by task, so that position i of the list belongs to range i % groups.  Each XCD then
+// works on one stretch of the trajectory and its L2 only has to hold that stretch's input spectra (1/groups of the set).
 inline void plan_seg_lpt(const std::vector<int64_t>& seg_start /*[P], last == T*/, int P, int C, int block, int jmax, int NP,
-                         std::vector<Task>& out, std::vector<int32_t>& scratch) {
+                         std::vector<Task>& out, std::vector<int32_t>& scratch, int groups = 1) {
     out.clear();
     constexpr int MAXCOST = 4096;
     auto cost = [NP](int j0, int nj) {
@@ -128,6 +132,81 @@ inline void plan_seg_lpt(const std::vector<int64_t>& seg_start /*[P], last == T*
         const int c = np_eff * (10 + 2 * nj) + 12 * nj;
         return c < MAXCOST ? c : MAXCOST - 1;
     };
+    if (groups > 1) {
+        static thread_local std::vector<Task> tmp;
+        static thread_local std::vector<int64_t> rowcost;
+        rowcost.assign((size_t)P + 1, 0);
+        // per-row cost and the range of every row
+        for (int r = 0; r < P; ++r) {
+            const int64_t a0 = seg_start[r > 0 ? r - 1 : r], a2 = seg_start[r < P - 1 ? r + 1 : r];
+            int64_t rc = 0;
+            if (a2 > a0) {
+                int64_t j = a0 / block;
+                const int64_t jhi = (a2 - 1) / block;
+                while (j <= jhi) {
+                    const int nj = (int)std::min<int64_t>(jmax, jhi - j + 1);
+                    rc += cost((int)j, nj);
+                    j += nj;
+                }
+            }
+            rowcost[(size_t)r + 1] = rowcost[(size_t)r] + rc;
+        }
+        const int64_t total_cost = rowcost[(size_t)P];
+        auto group_of = [&](int r) {
+            if (total_cost <= 0) return 0;
+            const int64_t mid = rowcost[(size_t)r] + (rowcost[(size_t)r + 1] - rowcost[(size_t)r]) / 2;
+            const int g = (int)((__int128)mid * groups / total_cost);
+            return g < groups ? g : groups - 1;
+        };
+        scratch.assign((size_t)groups * MAXCOST + groups + 1, 0);
+        int32_t* hist = scratch.data();                       // [groups][MAXCOST]
+        int32_t* gcount = scratch.data() + (size_t)groups * MAXCOST;
+        for (int r = 0; r < P; ++r) {
+            const int64_t a0 = seg_start[r > 0 ? r - 1 : r], a2 = seg_start[r < P - 1 ? r + 1 : r];
+            if (a2 <= a0) continue;
+            const int g = group_of(r);
+            int64_t j = a0 / block;
+            const int64_t jhi = (a2 - 1) / block;
+            while (j <= jhi) {
+                const int nj = (int)std::min<int64_t>(jmax, jhi - j + 1);
+                hist[(size_t)g * MAXCOST + cost((int)j, nj)] += C;
+                gcount[g] += C;
+                j += nj;
+            }
+        }
+        int32_t total = 0;
+        for (int g = 0; g < groups; ++g)
+            for (int c = MAXCOST - 1; c >= 0; --c) { int32_t& h = hist[(size_t)g * MAXCOST + c]; const int32_t n = h; h = total; total += n; }
+        tmp.resize((size_t)total);
+        for (int r = 0; r < P; ++r) {
+            const int64_t a0 = seg_start[r > 0 ? r - 1 : r], a2 = seg_start[r < P - 1 ? r + 1 : r];
+            if (a2 <= a0) continue;
+            const int g = group_of(r);
+            int64_t j = a0 / block;
+            const int64_t jhi = (a2 - 1) / block;
+            while (j <= jhi) {
+                const int nj = (int)std::min<int64_t>(jmax, jhi - j + 1);
+                int32_t& at = hist[(size_t)g * MAXCOST + cost((int)j, nj)];
+                for (int c = 0; c < C; ++c) {
+                    Task t;
+                    t.row = r; t.chan = c; t.j0 = (int32_t)j; t.nj = nj;
+                    tmp[(size_t)at++] = t;
+                }
+                j += nj;
+            }
+        }
+        // interleave: position i takes the next task of range i % groups (or of the next range that still has one)
+        out.resize((size_t)total);
+        int32_t next[64], end[64];
+        int32_t off = 0;
+        for (int g = 0; g < groups; ++g) { next[g] = off; off += gcount[g]; end[g] = off; }
+        for (int32_t i = 0; i < total; ++i) {
+            int g = i % groups;
+            for (int k = 0; k < groups && next[g] >= end[g]; ++k) g = (g + 1) % groups;
+            out[(size_t)i] = tmp[(size_t)next[g]++];
+        }
+        return;
+    }
     scratch.assign(MAXCOST + 1, 0);
     // pass 1: histogram of costs
     for (int r = 0; r < P; ++r) {

@@ -1123,7 +1123,9 @@ int render(int mode, const float* x, int64_t T, const float* bank, int32_t P, in
     }
     const bool fast_plan = g12 && mode == COEF_SEG;        // single-launch geometries, implicit schedule: O(P*C) direct planner
     if (fast_plan) {
-        plan_seg_lpt(c->seg_start, P, C, BB, JM, NPart, c->plan.tasks[0], c->plan_scratch);
+        // XCD-aware task order for the persistent assembly kernel (workgroup b -> XCD b % 8 takes tasks b, b + nwg, ...)
+        static const int plan_groups = getenv("SS_PLAN_GROUPS") ? atoi(getenv("SS_PLAN_GROUPS")) : 8;
+        plan_seg_lpt(c->seg_start, P, C, BB, JM, NPart, c->plan.tasks[0], c->plan_scratch, (g14 && plan_groups > 1 && plan_groups <= 64) ? plan_groups : 1);
         c->plan.tasks[1].clear();
     } else {
         if (mode == COEF_SEG) seg_minmax(c->seg_start, T, c->bmin, c->bmax);
