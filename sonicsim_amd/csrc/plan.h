@@ -114,6 +114,58 @@ inline void merge_lpt(Plan& plan, int NP, std::vector<Task>& out) {
     std::stable_sort(out.begin(), out.end(), [&](const Task& a, const Task& b) { return cost(a) > cost(b); });
 }
 
+// XCD-aware LPT order of the generic planner's lists (explicit schedule, fixed receiver) for the persistent kernels: see
+// plan_seg_lpt's `groups`.  Both parity lists come out of build_plan in time order (row, first block), so one linear merge gives
+// the time order; `groups` contiguous ranges of equal total cost; a counting sort by cost inside every range; ranges
+// interleaved task by task (position i <- range i % groups).  O(n), no allocation once the buffers have grown.
+inline void merge_lpt_xcd(Plan& plan, int NP, int groups, std::vector<Task>& out, std::vector<int32_t>& scratch) {
+    constexpr int MAXCOST = 4096;
+    auto cost = [NP](const Task& t) {
+        const int np_eff = std::min(NP, t.j0 + t.nj);
+        const int c = np_eff * (10 + 2 * t.nj) + 12 * t.nj;
+        return c < MAXCOST ? c : MAXCOST - 1;
+    };
+    static thread_local std::vector<Task> byt, tmp;
+    const std::vector<Task>&A = plan.tasks[0], &B = plan.tasks[1];
+    const size_t n = A.size() + B.size();
+    byt.resize(n);
+    auto before = [](const Task& a, const Task& b) { return a.row != b.row ? a.row < b.row : (a.j0 != b.j0 ? a.j0 < b.j0 : a.chan < b.chan); };
+    std::merge(A.begin(), A.end(), B.begin(), B.end(), byt.begin(), before);
+    if (!std::is_sorted(byt.begin(), byt.end(), before)) std::stable_sort(byt.begin(), byt.end(), before);   // (not expected)
+    int64_t total = 0;
+    for (const Task& t : byt) total += cost(t);
+    if (groups > 64) groups = 64;
+    if (groups < 1 || n < (size_t)groups * 2) groups = 1;
+    scratch.assign((size_t)groups * MAXCOST + groups + n, 0);
+    int32_t* hist = scratch.data();
+    int32_t* gcount = scratch.data() + (size_t)groups * MAXCOST;
+    int32_t* gof = gcount + groups;                                   // range of every task
+    int64_t acc = 0;
+    for (size_t i = 0; i < n; ++i) {
+        const int c = cost(byt[i]);
+        int g = total > 0 ? (int)((__int128)(acc + c / 2) * groups / total) : 0;
+        if (g >= groups) g = groups - 1;
+        gof[i] = g;
+        hist[(size_t)g * MAXCOST + c]++;
+        gcount[g]++;
+        acc += c;
+    }
+    int32_t run = 0;
+    for (int g = 0; g < groups; ++g)
+        for (int c = MAXCOST - 1; c >= 0; --c) { int32_t& h = hist[(size_t)g * MAXCOST + c]; const int32_t k = h; h = run; run += k; }
+    tmp.resize(n);
+    for (size_t i = 0; i < n; ++i) tmp[(size_t)hist[(size_t)gof[i] * MAXCOST + cost(byt[i])]++] = byt[i];
+    out.resize(n);
+    int32_t next[64], end[64];
+    int32_t off = 0;
+    for (int g = 0; g < groups; ++g) { next[g] = off; off += gcount[g]; end[g] = off; }
+    for (size_t i = 0; i < n; ++i) {
+        int g = (int)(i % (size_t)groups);
+        for (int k = 0; k < groups && next[g] >= end[g]; ++k) g = (g + 1) % groups;
+        out[i] = tmp[(size_t)next[g]++];
+    }
+}
+
 // Direct O(P*C) planner of the implicit (segment) schedule for the single-launch geometries (12/13/14): row r is responsible
 // for the samples [seg_start[r-1], seg_start[r+1]) (end filter of segment r-1, start filter of segment r -- SonicSim_moving.py
 // :89-94), i.e. for a run of consecutive output blocks, cut into tasks of at most `jmax` blocks.  Tasks come out in descending
@@ -123,8 +175,9 @@ inline void merge_lpt(Plan& plan, int NP, std::vector<Task>& out) {
 // the rows are cut into `groups` contiguous time ranges of equal total cost, every range is sorted by descending cost on its
 // own, and the ranges are interleaved task by task, so that position i of the list belongs to range i % groups.  Each XCD then
 // works on one stretch of the trajectory and its L2 only has to hold that stretch's input spectra (1/groups of the set).
+// nwg = number of persistent workgroups (0 = unknown: plain round-robin dealing).
 inline void plan_seg_lpt(const std::vector<int64_t>& seg_start /*[P], last == T*/, int P, int C, int block, int jmax, int NP,
-                         std::vector<Task>& out, std::vector<int32_t>& scratch, int groups = 1) {
+                         std::vector<Task>& out, std::vector<int32_t>& scratch, int groups = 1, int nwg = 0) {
     out.clear();
     constexpr int MAXCOST = 4096;
     auto cost = [NP](int j0, int nj) {
@@ -200,6 +253,12 @@ inline void plan_seg_lpt(const std::vector<int64_t>& seg_start /*[P], last == T*
         int32_t next[64], end[64];
         int32_t off = 0;
         for (int g = 0; g < groups; ++g) { next[g] = off; off += gcount[g]; end[g] = off; }
+        // the nwg / groups workgroups of a range take its list round-robin; dealing every second round in the opposite direction
+        // (boustrophedon) keeps the first workgroup from collecting the largest task of every round
+        const int bins = nwg > 0 && nwg % groups == 0 ? nwg / groups : 0;
+        if (bins > 1)
+            for (int g = 0; g < groups; ++g)
+                for (int32_t r0 = next[g] + bins; r0 + bins <= end[g]; r0 += 2 * bins) std::reverse(tmp.begin() + r0, tmp.begin() + r0 + bins);
         for (int32_t i = 0; i < total; ++i) {
             int g = i % groups;
             for (int k = 0; k < groups && next[g] >= end[g]; ++k) g = (g + 1) % groups;

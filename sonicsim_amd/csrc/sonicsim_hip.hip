@@ -1125,7 +1125,9 @@ int render(int mode, const float* x, int64_t T, const float* bank, int32_t P, in
     if (fast_plan) {
         // XCD-aware task order for the persistent assembly kernel (workgroup b -> XCD b % 8 takes tasks b, b + nwg, ...)
         static const int plan_groups = getenv("SS_PLAN_GROUPS") ? atoi(getenv("SS_PLAN_GROUPS")) : 8;
-        plan_seg_lpt(c->seg_start, P, C, BB, JM, NPart, c->plan.tasks[0], c->plan_scratch, (g14 && plan_groups > 1 && plan_groups <= 64) ? plan_groups : 1);
+        static const int plan_snake = getenv("SS_PLAN_SNAKE") ? atoi(getenv("SS_PLAN_SNAKE")) : 1;
+        plan_seg_lpt(c->seg_start, P, C, BB, JM, NPart, c->plan.tasks[0], c->plan_scratch, (g14 && plan_groups > 1 && plan_groups <= 64) ? plan_groups : 1,
+                     plan_snake ? c->num_cu : 0);
         c->plan.tasks[1].clear();
     } else {
         if (mode == COEF_SEG) seg_minmax(c->seg_start, T, c->bmin, c->bmax);
@@ -1137,7 +1139,8 @@ int render(int mode, const float* x, int64_t T, const float* bank, int32_t P, in
     // ---- upload plan blob: [seg_start (P int64)][tasks parity 0][tasks parity 1]
     //      geometry 12: ONE list in LPT order (atomic accumulation, persistent workgroups)
     if (g12 && !fast_plan) {
-        merge_lpt(c->plan, NPart, c->merged);
+        if (g14) merge_lpt_xcd(c->plan, NPart, 8, c->merged, c->plan_scratch);     // same XCD-aware order as the implicit schedule's planner
+        else merge_lpt(c->plan, NPart, c->merged);
         c->plan.tasks[0].swap(c->merged);
         c->plan.tasks[1].clear();
     }

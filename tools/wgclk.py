@@ -23,3 +23,7 @@ print("workgroups", ok.sum(), " span us %.1f" % us(en.max() - t0))
 print("start: median +%.1f  p90 +%.1f  max +%.1f us" % (us(np.median(st) - t0), us(np.percentile(st, 90) - t0), us(st.max() - t0)))
 print("end  : min %.1f  p10 %.1f  median %.1f  p90 %.1f  max %.1f us" % tuple(us(v - t0) for v in (en.min(), np.percentile(en, 10), np.median(en), np.percentile(en, 90), en.max())))
 print("busy per workgroup us: min %.1f median %.1f max %.1f" % (us((en - st).min()), us(np.median(en - st)), us((en - st).max())))
+busy = us(en - st)
+print("per XCD (wg % 8) median busy:", " ".join("%.1f" % np.median(busy[np.arange(len(busy)) % 8 == g]) for g in range(8)))
+print("per index band of 32 median busy:", " ".join("%.1f" % np.median(busy[b * 32:(b + 1) * 32]) for b in range(8)))
+print("6-task workgroups (index >= ntasks mod 256) median %.1f, others %.1f" % (np.median(busy[232:]), np.median(busy[:232])))
