@@ -114,3 +114,33 @@ def test_full_size_config2_asm(gpu):
     assert rel_rms(ys.cpu().numpy(), ops.convolve_fixed(x, bank[17], path="os4096").cpu().numpy()) < 2e-6
     nref = 60000
     assert_parity(ys[:, :nref].cpu().numpy(), moving.convolve_fixed_receiver(sc.x[:nref], bank[17].cpu().numpy()))
+
+
+def test_random_shape_sweep(gpu):
+    """Seeded random sweep over (T, P, C, L) and segment layouts (zero-length segments, one-sample segments, segments much
+    longer / shorter than a 4096-sample block) on the default engine: implicit schedule vs the oracle, and the explicit
+    (idx, w) entry point bit-identical to it."""
+    from sonicsim_amd import ops
+    rng = np.random.default_rng(2024)
+    for case in range(24):
+        T = int(rng.integers(4200, 70000))
+        P = int(rng.integers(2, 14))
+        C = int(rng.integers(1, 5))
+        L = int(rng.choice([129, 300, 4095, 4096, 4097, 8192, 9000, 12288, 15000]))
+        x, bank, _ = golden_inputs(1000 + case, T, P, C, L)
+        # random segment lengths summing to T: a few zeros and ones, the rest proportional to random weights
+        wts = rng.random(P - 1) ** 3 + 1e-3
+        wts[rng.random(P - 1) < 0.2] = 0.0
+        if wts.sum() == 0:
+            wts[0] = 1.0
+        seg = np.floor(wts / wts.sum() * T).astype(np.int64)
+        ones = np.flatnonzero(rng.random(P - 1) < 0.1)
+        seg[ones] = np.minimum(seg[ones], 1)
+        seg[np.argmax(wts)] += T - seg.sum()
+        assert seg.sum() == T and (seg >= 0).all()
+        idx = np.repeat(np.arange(P - 1), seg)
+        w = np.concatenate([np.linspace(0, 1, n, endpoint=False) for n in seg]).astype(np.float32) if T else np.zeros(0, np.float32)
+        ref = moving.convolve_moving_receiver(x, bank, idx, w)
+        y = ops.convolve_moving_seg(x, bank, seg)
+        assert_parity(y, ref)
+        assert np.array_equal(ops.convolve_moving(x, bank, idx, w), y), (case, T, P, C, L)
