@@ -279,8 +279,24 @@ __device__ __forceinline__ double rms_db_from_sumsq(double ss_, double n) {
     return 10.0 * log10(ms > 1e-20 ? ms : 1e-20);
 }
 
-// mix step 2: interferer gains from speaker energies (movingdatamodule.py:106-113)
-__global__ void k_mix_gains1(const double* __restrict__ sumsq, int S, double n, const float* __restrict__ sirs, float* __restrict__ g) {
+// one wave adds nb partial sums in k_final_sum's association (64 strided lanes, then a butterfly); every lane gets the sum
+__device__ __forceinline__ double wave_final_sum(const double* __restrict__ partial, int nb, int lane) {
+    double s = 0.0;
+    for (int i = lane; i < nb; i += 64) s += partial[i];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    return s;
+}
+// mix step 2: interferer gains from speaker energies (movingdatamodule.py:106-113); finishes the energy sums itself
+// (partial[S][nb], wave per speaker) instead of a separate final-sum launch
+__global__ __launch_bounds__(1024) void k_mix_gains1(const double* __restrict__ partial, int nb, int S, double n, const float* __restrict__ sirs,
+                                                     float* __restrict__ g, double* __restrict__ sumsq_out) {
+    __shared__ double sumsq[64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int sp = w; sp < S; sp += 16) {
+        const double v = wave_final_sum(partial + (int64_t)sp * nb, nb, lane);
+        if (lane == 0) { sumsq[sp] = v; sumsq_out[sp] = v; }
+    }
+    __syncthreads();
     const int i = threadIdx.x;
     if (i == 0) g[0] = 1.0f;
     if (i >= 1 && i < S) {
@@ -318,7 +334,13 @@ __global__ __launch_bounds__(256) void k_mix_scale_sum(float* __restrict__ spk, 
         partial[gridDim.x + blockIdx.x] = (sw[1][0] + sw[1][1]) + (sw[1][2] + sw[1][3]);
     }
 }
-__global__ void k_mix_gains2(const double* __restrict__ sums /*[2]*/, double n, float snr, float* __restrict__ g, int S) {
+__global__ __launch_bounds__(128) void k_mix_gains2(const double* __restrict__ partial /*[2][nb]: speech, noise*/, int nb, double n, float snr,
+                                                    float* __restrict__ g, int S) {
+    __shared__ double sums[2];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const double v = wave_final_sum(partial + (int64_t)w * nb, nb, lane);
+    if (lane == 0) sums[w] = v;
+    __syncthreads();
     if (threadIdx.x == 0) {
         double gain = rms_db_from_sumsq(sums[0], n) - rms_db_from_sumsq(sums[1], n) - (double)snr;
         gain = gain < 40.0 ? gain : 40.0;
@@ -1492,12 +1514,10 @@ int ss_mix_f32(float* speakers, int32_t S, const float* noises, int32_t N, int64
         pin->pending = true;
     }
     hipLaunchKernelGGL(k_partial_sum<0>, dim3(nb, S), dim3(256), 0, stream, (const float*)dspk, n, (double*)c->ws[WS_SCR]);
-    hipLaunchKernelGGL(k_final_sum, dim3(S), dim3(64), 0, stream, (const double*)c->ws[WS_SCR], nb, d_sumsq);
-    hipLaunchKernelGGL(k_mix_gains1, dim3(1), dim3(64), 0, stream, (const double*)d_sumsq, S, (double)n, (const float*)d_sir, d_g);
+    hipLaunchKernelGGL(k_mix_gains1, dim3(1), dim3(1024), 0, stream, (const double*)c->ws[WS_SCR], nb, S, (double)n, (const float*)d_sir, d_g, d_sumsq);
     hipLaunchKernelGGL(k_mix_scale_sum, dim3(nb), dim3(256), 0, stream, dspk, S, dnoise, N, n, (const float*)d_g, dmix,
                        (double*)c->ws[WS_SCR]);
-    hipLaunchKernelGGL(k_final_sum, dim3(2), dim3(64), 0, stream, (const double*)c->ws[WS_SCR], nb, d_s2);
-    hipLaunchKernelGGL(k_mix_gains2, dim3(1), dim3(64), 0, stream, (const double*)d_s2, (double)n, snr, d_g, S);
+    hipLaunchKernelGGL(k_mix_gains2, dim3(1), dim3(128), 0, stream, (const double*)c->ws[WS_SCR], nb, (double)n, snr, d_g, S);
     hipLaunchKernelGGL(k_mix_final, dim3(grid_for(n)), dim3(256), 0, stream, dnoise, N, n, (const float*)d_g, S, dmix);
     HIPCHK(hipGetLastError());
     if (gains_out) {
