@@ -1536,6 +1536,11 @@ int ss_mix_f32(float* speakers, int32_t S, const float* noises, int32_t N, int64
 
 // K-weighting coefficients -> KwCoef (normalised biquads + the powers of the chunk transition matrix the scan needs)
 static int kw_setup(const double* coef, KwCoef& k) {
+    // the tables depend on the 12 coefficients only (one set per sample rate): reuse the last set's tables
+    static double last_coef[12];
+    static KwCoef last_k;
+    static bool have_last = false;
+    if (have_last && memcmp(last_coef, coef, sizeof(last_coef)) == 0) { k = last_k; return SS_OK; }
     for (int s = 0; s < 2; ++s) {
         const double a0 = coef[s * 6 + 3];
         if (a0 == 0.0) return fail(SS_EINVAL, "a0 == 0");
@@ -1576,6 +1581,9 @@ static int kw_setup(const double* coef, KwCoef& k) {
                 for (int m = 0; m < 4; ++m) acc += k.Mp[i - 1][r * 4 + m] * k.Mp[i - 1][m * 4 + q];
                 k.Mp[i][r * 4 + q] = acc;
             }
+    memcpy(last_coef, coef, sizeof(last_coef));
+    last_k = k;
+    have_last = true;
     return SS_OK;
 }
 
