@@ -7,7 +7,7 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 BENCH="python bench.py --steps 5 --warmup 2 --cpu-positions 0"
 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/stats -o stats -f csv -- $BENCH > $OUT/stats.log 2>&1
-run_pmc () { local name=$1; shift; timeout 300 rocprofv3 --kernel-trace --pmc "$@" -d $OUT/pmc_$name -o pmc -f csv -- $BENCH > $OUT/pmc_$name.log 2>&1; }
+run_pmc () { local name=$1; shift; BENCH_PREWARM_MS=0 timeout 300 rocprofv3 --kernel-trace --pmc "$@" -d $OUT/pmc_$name -o pmc -f csv -- $BENCH > $OUT/pmc_$name.log 2>&1; }
 run_pmc sq1 SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS
 run_pmc sq2 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR
 run_pmc tcc TCC_HIT_sum TCC_MISS_sum

@@ -7,7 +7,7 @@ OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 BENCH="python bench.py --steps 10 --warmup 2 --cpu-positions 0"
-BENCH_PMC="python bench.py --steps 3 --warmup 1 --cpu-positions 0"
+BENCH_PMC="env BENCH_PREWARM_MS=0 python bench.py --steps 3 --warmup 1 --cpu-positions 0"     # counters do not need the sustained state
 echo "== kernel-trace --stats" 
 timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/stats -o stats -f csv -- $BENCH > $OUT/stats.log 2>&1
 tail -2 $OUT/stats.log
