@@ -12,7 +12,7 @@ dev = torch.device("cuda:0")
 ops.init(0)
 
 
-def timeit(fn, n=10, warm=2):
+def timeit(fn, n=20, warm=3):
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
@@ -24,6 +24,17 @@ def timeit(fn, n=10, warm=2):
 
 
 out = {}
+# sustained state first (clock ramp-up costs a fresh process 10-15 % on its first renders, see bench.py)
+_sc = synth.make_scene("cfg2", scene=0)
+_seg = synth.scene_segments(_sc, 0)
+_bank = ops.rir_bank_synth(_sc.delay, _sc.dgain, _sc.L, _sc.fs, _sc.rt60, _sc.bank_seed, device=dev)
+_x = torch.from_numpy(_sc.x).to(dev)
+_t = time.perf_counter()
+while time.perf_counter() - _t < 0.1:
+    for _ in range(10):
+        ops.convolve_moving_seg(_x, _bank, _seg)
+    torch.cuda.synchronize()
+del _bank, _x
 # config 5: FOA, 120 s @ 48 kHz, P=500, L=96000
 sc = synth.make_scene("cfg5", scene=0)
 seg = synth.scene_segments(sc, 0)
