@@ -110,6 +110,10 @@ def main():
     # untimed pre-roll until the device is in its sustained state: the first ~30 renders of a fresh process run 10-15 % slower
     # (clock ramp-up; the caching allocator still creating the output blocks the 4-deep launch pipeline cycles through).
     # Not part of the W warm-up steps or the K timed steps; BENCH_PREWARM_MS=0 disables it.
+    if world > 1:
+        dist.barrier()                 # align the ranks first, so that the barrier in front of the timed region is short
+        if not args.no_gather:         # untimed: RCCL builds its point-to-point channels on first use (before the pre-roll: it idles the GPU)
+            parallel.gather_to_root(step(), dst=0)
     prewarm_ms = float(os.environ.get("BENCH_PREWARM_MS", "80"))
     prewarm_steps = 0
     t_pre = time.perf_counter()
@@ -121,10 +125,6 @@ def main():
     y = None
     for _ in range(args.warmup):
         y = step()
-    if world > 1 and not args.no_gather:
-        if y is None:
-            y = step()
-        parallel.gather_to_root(y, dst=0)          # untimed: RCCL builds its point-to-point channels on first use
     torch.cuda.synchronize()
     # HIP events bracket every 2nd launch of the render kernel inside the timed region (an event pair is two barrier packets
     # = a few us of launch gap per step); BENCH_PROF_EVERY=1 times every launch, BENCH_NOPROF=1 none (diagnostics)
