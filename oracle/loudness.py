@@ -10,7 +10,9 @@ published algorithm (ITU-R BS.1770-4 as implemented by pyloudnorm 0.1.x ``meter.
 
   * K-weighting = high-shelf biquad (G=4 dB, Q=1/sqrt2, fc=1500 Hz) then high-pass biquad
     (G=0, Q=0.5, fc=38 Hz), RBJ-style coefficient formulas evaluated at the actual rate,
-    applied with ``scipy.signal.lfilter`` in float64, channel by channel.
+    applied with ``scipy.signal.lfilter`` (float64 arithmetic), channel by channel, each stage's result
+    assigned back into a copy of the input array -- i.e. rounded to the INPUT dtype between the stages
+    (float32 for the audio SonicSet.py passes; see ``integrated_loudness``).
   * gating blocks T_g=0.4 s, 75 % overlap; block j covers samples
     [int(T_g*(j*step)*rate), int(T_g*(j*step+1)*rate)); z[i,j] = sum(x^2)/(T_g*rate);
     l_j = -0.691 + 10 log10(sum_i G_i z_ij), G = [1,1,1,1.41,1.41];
@@ -88,12 +90,20 @@ def gate(z, weights):
     return float(lufs)
 
 
-def integrated_loudness(data, rate, block_size=0.4, allow_many_channels=False):
-    """pyloudnorm Meter(rate, block_size).integrated_loudness(data); data (T,) or (T,C) float."""
+def integrated_loudness(data, rate, block_size=0.4, allow_many_channels=False, mirror_dtype=True):
+    """pyloudnorm Meter(rate, block_size).integrated_loudness(data); data (T,) or (T,C) float.
+
+    ``mirror_dtype=True`` follows pyloudnorm's dtype behaviour (recalled from pyloudnorm 0.1.x ``meter.py``; the package is
+    absent, so this too is unpinned): the meter works on ``input_data = data.copy()`` and assigns every filter stage's
+    float64 ``lfilter`` output back INTO that array, ``input_data[:, ch] = stage.apply_filter(input_data[:, ch])``.  For the
+    float32 audio SonicSet.py:97-101 passes, the signal is therefore rounded to float32 after the high-shelf stage and again
+    after the high-pass stage, and the block energies ``np.sum(np.square(input_data[l:u, i]))`` are float32 pairwise sums.
+    float64 input (or ``mirror_dtype=False``) runs everything in float64 -- the mathematically cleaner value the device
+    path computes; the two differ by ~1e-7 relative in z (~1e-6 dB)."""
     data = np.asarray(data)
     if not np.issubdtype(data.dtype, np.floating):
         raise ValueError("Data must be floating point.")
-    x = data.astype(np.float64, copy=True)
+    x = data.copy() if mirror_dtype else data.astype(np.float64, copy=True)
     if x.ndim == 1:
         x = x.reshape(-1, 1)
     n, nch = x.shape
@@ -104,7 +114,7 @@ def integrated_loudness(data, rate, block_size=0.4, allow_many_channels=False):
     weights = G_WEIGHTS if nch <= 5 else [1.0] * nch
     for (b, a) in k_weighting_coeffs(rate):
         for ch in range(nch):
-            x[:, ch] = signal.lfilter(b, a, x[:, ch])
+            x[:, ch] = signal.lfilter(b, a, x[:, ch])          # float64 result, stored in x's dtype
     lo, hi = block_bounds(n, rate, block_size)
     z = np.zeros((nch, len(lo)))
     for i in range(nch):
@@ -113,21 +123,27 @@ def integrated_loudness(data, rate, block_size=0.4, allow_many_channels=False):
     return gate(z, weights)
 
 
-def lufs_norm(data, sr, norm=-6, allow_many_channels=False):
-    """SonicSim_audio.py:68-81."""
+def lufs_norm(data, sr, norm=-6, allow_many_channels=False, mirror_dtype=True):
+    """SonicSim_audio.py:68-81.  ``pyln.normalize.loudness`` is ``gain * data`` with ``gain = np.power(10.0, delta / 20.0)``
+    (a float64 NumPy scalar): under the NumPy 1.x the reference pins (``ss-2.0.yaml``: numpy 1.23.5) a float32 array times
+    that scalar stays float32 -- ``fl32(fl32(gain) * x)``, which is what ``mirror_dtype`` reproduces (NumPy 2 would promote to
+    float64)."""
     data = np.asarray(data)
     block_size = 0.4 if len(data) / sr >= 0.4 else len(data) / sr
-    loudness = integrated_loudness(data, sr, block_size, allow_many_channels=allow_many_channels)
+    loudness = integrated_loudness(data, sr, block_size, allow_many_channels=allow_many_channels, mirror_dtype=mirror_dtype)
     if math.isinf(loudness):
         loudness = -40
     gain_lin = np.power(10.0, (norm - loudness) / 20.0)          # pyln.normalize.loudness
-    norm_data = gain_lin * data
+    if mirror_dtype and data.dtype == np.float32:
+        norm_data = np.float32(gain_lin) * data
+    else:
+        norm_data = gain_lin * data
     n, d = np.sum(np.array(norm_data)), np.sum(np.array(data))
     gain = n / d if d else 0.0
     return norm_data, gain
 
 
-def get_lufs_norm_audio(audio, sr=16000, lufs=-6, allow_many_channels=False):
+def get_lufs_norm_audio(audio, sr=16000, lufs=-6, allow_many_channels=False, mirror_dtype=True):
     """SonicSim_audio.py:83-86 (draws the target from the GLOBAL NumPy RNG like the reference)."""
     class_lufs = np.random.uniform(lufs - 2, lufs + 2)
-    return lufs_norm(audio, sr, class_lufs, allow_many_channels=allow_many_channels)
+    return lufs_norm(audio, sr, class_lufs, allow_many_channels=allow_many_channels, mirror_dtype=mirror_dtype)

@@ -91,6 +91,16 @@ def clip_all(audio_list):
     return [a[..., :m] for a in audio_list]
 
 
+def all_pairs_order(num_sources, num_receivers, rotations):
+    """SonicSim_audio.py:88-109 + :372-374: the (source, receiver) index pairs in the order the provider is called
+    (itertools.product: source-major), and the rotation handed to each pair -- all_pairs(sources, rotations)[1], i.e. the
+    rotation list is ALSO paired per source (with one receiver and one rotation, SonicSet.py:61-63, this is the identity)."""
+    src = [s for s in range(num_sources) for _ in range(num_receivers)]
+    rcv = [r for _ in range(num_sources) for r in range(num_receivers)]
+    rot = [q for _ in range(num_sources) for q in rotations]
+    return src, rcv, rot
+
+
 def stack_and_normalise(ir_list, num_sources, num_receivers):
     """SonicSim_audio.py:391-398: clip_all -> stack -> reshape (S,R,C,L) -> /= abs().max() (global)."""
     ir_list = clip_all(ir_list)

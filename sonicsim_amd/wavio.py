@@ -12,18 +12,23 @@ import numpy as np
 
 
 def save(path: str, wav, sample_rate: int) -> None:
-    """wav: (C, T) or (T,) float32 (NumPy or CPU/ROCm torch tensor), channel-first like torchaudio."""
+    """wav: (C, T) or (T,) float32 (NumPy or CPU/ROCm torch tensor), channel-first like torchaudio.
+    Container layout = what torchaudio wrote for the reference's fixtures (``separation/tests/noise/*.wav``): 18-byte ``fmt ``
+    chunk (WAVE_FORMAT_IEEE_FLOAT, cbSize 0), ``fact`` chunk with the frame count, ``data``; a load -> save round trip of
+    those files is byte-identical (tests/test_formats.py)."""
     if hasattr(wav, "detach"):
         wav = wav.detach().cpu().numpy()
     a = np.asarray(wav, dtype=np.float32)
     if a.ndim == 1:
         a = a[None, :]
     C, T = a.shape
-    data = np.ascontiguousarray(a.T).tobytes()          # interleaved frames
-    fmt = struct.pack("<HHIIHH", 3, C, int(sample_rate), int(sample_rate) * C * 4, C * 4, 32)
+    data = np.ascontiguousarray(a.T).astype("<f4", copy=False).tobytes()          # interleaved frames
+    fmt = struct.pack("<HHIIHHH", 3, C, int(sample_rate), int(sample_rate) * C * 4, C * 4, 32, 0)
     fact = struct.pack("<I", T)
     body = (b"WAVE" + b"fmt " + struct.pack("<I", len(fmt)) + fmt + b"fact" + struct.pack("<I", 4) + fact
             + b"data" + struct.pack("<I", len(data)) + data)
+    if len(data) & 1:
+        body += b"\x00"
     with open(path, "wb") as f:
         f.write(b"RIFF" + struct.pack("<I", len(body)) + body)
 

@@ -11,6 +11,9 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the restated dataset arithmetic mixes NumPy scalars with torch tensors exactly like the reference does; NumPy 2 warns
+    # about torch's __array_wrap__ signature there
+    config.addinivalue_line("filterwarnings", "ignore:__array_wrap__ must accept context:DeprecationWarning")
 
 
 @pytest.fixture(scope="session")
@@ -28,3 +31,4 @@ def gpu(built_lib):
     from sonicsim_amd import ops
     ops.init(0)
     return torch.device("cuda:0")
+

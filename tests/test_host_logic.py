@@ -143,3 +143,20 @@ def test_synth_scene_shapes():
     assert seg.sum() == sc.T and seg.shape == (sc.P - 1,)
     c2 = synth.CONFIGS["cfg2"]
     assert (c2["T"], c2["P"], c2["C"], c2["L"], c2["fs"]) == (960000, 200, 8, 48000, 16000)
+
+
+def test_loudness_oracle_mirrors_input_dtype():
+    """pyloudnorm filters IN the (copied) input array: float32 audio is rounded to float32 between the K-weighting stages and
+    its block energies are float32 sums; float64 audio runs in float64.  The two agree to ~1e-6 dB (and the normalised float32
+    output keeps its dtype, as under the NumPy 1.x the reference pins)."""
+    from oracle import loudness as O
+    rng = np.random.default_rng(5)
+    a = (rng.standard_normal((48000, 2)) * 0.05).astype(np.float32)
+    l32 = O.integrated_loudness(a, 16000)
+    l64 = O.integrated_loudness(a.astype(np.float64), 16000)
+    assert l32 != l64 and abs(l32 - l64) < 1e-5
+    assert O.integrated_loudness(a, 16000, mirror_dtype=False) == l64
+    n32, _ = O.lufs_norm(a, 16000, -20)
+    n64, _ = O.lufs_norm(a.astype(np.float64), 16000, -20)
+    assert n32.dtype == np.float32 and n64.dtype == np.float64
+    np.testing.assert_allclose(n32, n64, rtol=2e-7, atol=0)

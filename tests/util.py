@@ -41,3 +41,33 @@ def assert_parity(y, ref, tol=TOL, per_channel=True):
             rc = rel_rms(y[c], ref[c])
             assert rc <= tol, f"channel {c}: rel RMS {rc:.3e} > {tol}"
     return r
+
+
+# ---- seed-regenerable synthetic providers shared by tests/golden/make_golden_aux.py (the stubbed torchaudio.load /
+# render_rir_parallel of the reference run) and the tests that replay those goldens.  NumPy's PCG64 stream is stable.
+def golden_stem(rel_path, C, T):
+    """(C, T) float32 'file content' of a stem, keyed by its path relative to the dataset root.  Speaker stems
+    (moving_audio_*.wav) are gated (0.2-0.8 s utterances, 0.5-2.5 s near-silent gaps) so that the -40 dB silence rejection really rejects crops."""
+    import zlib
+    rel_path = rel_path.replace(os.sep, "/")
+    rng = np.random.default_rng(zlib.crc32(rel_path.encode()))
+    x = (0.05 * rng.standard_normal((C, T))).astype(np.float32)
+    if "moving_audio" in rel_path:
+        gate = np.full(T, 2e-3, dtype=np.float32)          # -80 dB floor between the utterances
+        t, on = 0, bool(rng.integers(0, 2))
+        while t < T:
+            n = int((rng.uniform(0.2, 0.8) if on else rng.uniform(0.5, 2.5)) * 16000)
+            if on:
+                gate[t:t + n] = 1.0
+            on = not on
+            t += n
+        x *= gate[None, :]
+    return x
+
+
+def golden_ir(case, i, C):
+    """(C, L_i) float32 impulse response number i of golden case `case`; lengths are ragged (clip_all must crop)."""
+    L = 900 + 37 * ((i * 7 + case * 3) % 11)
+    rng = np.random.default_rng(9000 + 100 * case + i)
+    h = rng.standard_normal((C, L)) * np.exp(-np.arange(L) / 200.0)[None, :]
+    return h.astype(np.float32)
