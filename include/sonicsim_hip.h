@@ -69,6 +69,15 @@ int ss_convolve_moving_f32(const float* x, int64_t T, const float* rirs, int32_t
 int ss_convolve_moving_seg_f32(const float* x, int64_t T, const float* rirs, int32_t P, int32_t C, int32_t L,
                                const int64_t* seg_len, float* y, uint32_t flags, void* stream);
 
+/* ---- rows G+I+V: SonicSim_audio.py:398 deferred into SonicSim_moving.py:63-96 ----------------
+ * y = render of (rirs / *divisor).  The global peak normalisation of a bank is one scalar and the render is linear in the
+ * filters, so a bank that is only rendered -- never handed back -- need not be rewritten: the scalar
+ * is applied to the dry signal while its spectra are formed.  Device pointers only (SS_FLAG_DEVICE_PTR); `divisor` is a
+ * device float (e.g. the peak ss_rir_bank_synth_peak_f32 left).  Differs from rendering the materialised bank by float32
+ * round-off only (1e-7 relative). */
+int ss_convolve_moving_seg_div_f32(const float* x, int64_t T, const float* rirs, int32_t P, int32_t C, int32_t L,
+                                   const int64_t* seg_len, const float* divisor, float* y, uint32_t flags, void* stream);
+
 /* ---- row F: SonicSim_moving.py:47-61  convolve_fixed_receiver --------------------------------
  * y[c,t] = (x * h[c])[t], 0 <= t < T.   h[C][L]. Replaces scipy.signal.fftconvolve(...)[:, :T]. */
 int ss_convolve_fixed_f32(const float* x, int64_t T, const float* h, int32_t C, int32_t L, float* y,
@@ -92,12 +101,21 @@ typedef struct SsRirParams {
     const float* dgain;   /* [P][C] direct-path gain (host)                  */
 } SsRirParams;
 int ss_rir_bank_synth_f32(const SsRirParams* prm, float* bank, uint32_t flags, void* stream);
+/* The same, and max |bank| (the abs().max() of SonicSim_audio.py:398) leaves the generator with the bank: a wave reduction
+ * plus one atomic max per wave inside the generating kernel instead of a second pass over the bank.  `peak` follows flags bit 0
+ * (device float: no synchronisation; host float: returned with the bank). */
+int ss_rir_bank_synth_peak_f32(const SsRirParams* prm, float* bank, float* peak, uint32_t flags, void* stream);
 
 /* ---- row G: SonicSim-SonicSet/SonicSim_audio.py:398  ir_output /= ir_output.abs().max() -------
  * In-place global peak normalisation (IEEE float32 division, bit-exact with the reference's
  * elementwise true division).  peak_out (HOST pointer, may be NULL) receives the peak; asking for
- * it synchronises the stream.  A zero peak leaves the data unchanged and returns SS_OK. */
+ * it synchronises the stream.  Degenerate banks behave like the reference: an all-zero bank becomes NaN (0/0), a NaN anywhere
+ * makes everything NaN. */
 int ss_peak_normalize_f32(float* data, int64_t n, float* peak_out, uint32_t flags, void* stream);
+/* data /= *divisor with a divisor that is already known (ss_rir_bank_synth_peak_f32): the single pass that materialises the
+ * normalised bank of SonicSim_audio.py:398 when the caller wants the bank itself (SonicSet.py:68 saves it).  `divisor`
+ * follows flags bit 0.  Same IEEE division, same bits as ss_peak_normalize_f32. */
+int ss_divide_by_f32(float* data, int64_t n, const float* divisor, uint32_t flags, void* stream);
 
 /* ---- row M: separation/look2hear/datas/movingdatamodule.py:29-32 compute_mch_rms_dB ----------
  * out_db[i] = 10*log10(max(1e-20, mean(x_i^2))) over ALL n elements of each of `count` equally

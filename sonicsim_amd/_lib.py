@@ -49,7 +49,13 @@ _SIGS = {
     "ss_convolve_fixed_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32,
                                              ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p]),
     "ss_rir_bank_synth_f32": (ctypes.c_int, [ctypes.POINTER(SsRirParams), ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p]),
+    "ss_rir_bank_synth_peak_f32": (ctypes.c_int, [ctypes.POINTER(SsRirParams), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32,
+                                                  ctypes.c_void_p]),
     "ss_peak_normalize_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, c_f32p, ctypes.c_uint32, ctypes.c_void_p]),
+    "ss_divide_by_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p]),
+    "ss_convolve_moving_seg_div_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32,
+                                                      ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32,
+                                                      ctypes.c_void_p]),
     "ss_rms_db_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, c_f64p, ctypes.c_uint32, ctypes.c_void_p]),
     "ss_mix_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, c_f32p,
                                   ctypes.c_float, ctypes.c_void_p, c_f32p, ctypes.c_uint32, ctypes.c_void_p]),

@@ -68,13 +68,14 @@ template <int ABL = 0> __global__ __launch_bounds__(512, 2) void k_os12(RenderPa
 }
 
 // input spectra for the assembly / geometry-13 render kernels (no zero spectrum: their descriptors return zeros out of range)
+// counter: task-queue heads of the render kernel that follows -- ncnt words, 64 bytes apart, each set to cnt_init
 __global__ __launch_bounds__(512, 2) void k_xspec13(const float* __restrict__ x, int64_t T, const c32* __restrict__ consts,
                                                     c32* __restrict__ Xs, int M, float* __restrict__ yzero, int64_t nzero,
-                                                    int* __restrict__ counter) {
+                                                    int* __restrict__ counter, int ncnt, int cnt_init, const float* __restrict__ xdiv) {
     __shared__ __attribute__((aligned(16))) c32 smem[LDS13_C32];
     DevEnv env{smem};
-    if (counter && blockIdx.x == 0 && threadIdx.x == 0) *counter = 0;
-    xspec13_body(env, x, T, consts, Xs, (int)blockIdx.x, M, yzero, nzero);
+    if (counter && blockIdx.x == 0 && (int)threadIdx.x < ncnt) counter[16 * threadIdx.x] = cnt_init;
+    xspec13_body(env, x, T, consts, Xs, (int)blockIdx.x, M, yzero, nzero, xdiv);
 }
 
 // geometry 13 (tvfir13.h): software-pipelined FFT/MAC, one barrier per transform, buffer addressing, dynamic task queue
@@ -145,53 +146,121 @@ __device__ __forceinline__ uint32_t hash32(uint32_t seed, uint32_t stream, uint6
     uint32_t h = fmix32((uint32_t)(ctr >> 32) ^ k);
     return fmix32((uint32_t)ctr ^ h);
 }
-__device__ __forceinline__ float gauss_hash(uint32_t seed, uint64_t ctr) {
-    const float u1 = ((float)(hash32(seed, 1u, ctr) >> 8) + 0.5f) * 5.9604644775390625e-8f;
-    const float u2 = ((float)(hash32(seed, 2u, ctr) >> 8) + 0.5f) * 5.9604644775390625e-8f;
-    return sqrtf(-2.0f * logf(u1)) * cospif(2.0f * u2);
+__device__ __forceinline__ float unit24(uint32_t h) { return ((float)(h >> 8) + 0.5f) * 5.9604644775390625e-8f; }
+// Box-Muller on two 24-bit uniforms with the hardware transcendentals (v_log_f32 = log2, v_cos_f32 takes revolutions):
+// sqrt(-2 ln u1) cos(2 pi u2)
+__device__ __forceinline__ float box_muller(float u1, float u2) {
+    return __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1)) * __builtin_amdgcn_cosf(u2);
 }
 
-__global__ __launch_bounds__(256) void k_rir_synth(RirDev p, float* __restrict__ bank) {
+// FAST32: the whole bank has fewer than 2^32 samples, so the high counter word is 0 for every sample and the first
+// mixing round of hash32 is one constant per stream (computed once per thread).  peak_bits (may be null): bit pattern of
+// max |bank| over the whole bank (non-negative floats order like their bit patterns) -- row G's abs().max() for free.
+template <bool FAST32>
+__global__ __launch_bounds__(256) void k_rir_synth(RirDev p, float* __restrict__ bank, unsigned int* __restrict__ peak_bits) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t CL = (int64_t)p.C * p.L;
-    if (i >= CL) return;
-    const int c = (int)(i / p.L);
-    const int t = (int)(i - (int64_t)c * p.L);
+    const bool live = i < CL;
+    const int64_t ii = live ? i : CL - 1;
+    const int c = (int)(ii / p.L);
+    const int t = (int)(ii - (int64_t)c * p.L);
     const float env = (float)exp(-(double)t * p.inv_tau);
     const float te = p.tail_gain * env;
-    float n = 0.0f;
+    const uint32_t k1 = p.seed * 0x9E3779B9u + 1u, k2 = p.seed * 0x9E3779B9u + 2u;
+    const uint32_t h1c = fmix32(k1), h2c = fmix32(k2);
+    float n = 0.0f, peak = 0.0f;
+    uint64_t ctr = (uint64_t)c * (uint64_t)p.L + (uint64_t)t;
+    float* out = bank + ii;
+    const int32_t* dl = p.delay + c;
+    const float* dg = p.dgain + c;
     for (int q = 0; q < p.P; ++q) {
-        const uint64_t ctr = ((uint64_t)q * (uint64_t)p.C + (uint64_t)c) * (uint64_t)p.L + (uint64_t)t;
-        const float g = gauss_hash(p.seed, ctr);
+        uint32_t a1, a2;
+        if (FAST32) {
+            a1 = fmix32((uint32_t)ctr ^ h1c);
+            a2 = fmix32((uint32_t)ctr ^ h2c);
+        } else {
+            a1 = fmix32((uint32_t)ctr ^ fmix32((uint32_t)(ctr >> 32) ^ k1));
+            a2 = fmix32((uint32_t)ctr ^ fmix32((uint32_t)(ctr >> 32) ^ k2));
+        }
+        const float g = box_muller(unit24(a1), unit24(a2));
         n = (q == 0) ? g : (p.rho * n + p.srho * g);
-        const int d = p.delay[q * p.C + c];
+        const int d = dl[(int64_t)q * p.C];
         float v = (t > d) ? te * n : 0.0f;
-        if (t == d) v += p.dgain[q * p.C + c];
-        bank[((int64_t)q * p.C + c) * p.L + t] = v;
+        if (t == d) v += dg[(int64_t)q * p.C];
+        if (live) *out = v;
+        peak = fmaxf(peak, fabsf(v));
+        out += CL;
+        ctr += (uint64_t)CL;
+    }
+    if (peak_bits) {
+        if (!live) peak = 0.0f;
+        for (int o = 32; o > 0; o >>= 1) peak = fmaxf(peak, __shfl_xor(peak, o));
+        if ((threadIdx.x & 63) == 0 && peak > 0.0f) atomicMax(peak_bits, __float_as_uint(peak));
     }
 }
 
 // ---------------------------------------------------------------------------------------------
 // reductions / elementwise (rows G, M, U)
+// 16-byte loads, 8 independent loads in flight per thread: a pure streaming max must run at the copy ceiling
 __global__ __launch_bounds__(256) void k_absmax(const float* __restrict__ x, int64_t n, unsigned int* __restrict__ out_bits) {
     unsigned int m = 0;
-    const int64_t stride = (int64_t)gridDim.x * 256;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
-        const unsigned int b = __float_as_uint(x[i]) & 0x7fffffffu;
-        m = b > m ? b : m;
+    const int64_t stride = (int64_t)gridDim.x * 256, tid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    int64_t head = 0;
+    if (((uintptr_t)x & 15) == 0) {
+        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4* x4 = reinterpret_cast<const u32x4*>(x);
+        const int64_t n4 = n >> 2;
+        int64_t i = tid;
+        for (; i + 7 * stride < n4; i += 8 * stride) {
+            u32x4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = __builtin_nontemporal_load(x4 + i + u * stride);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const unsigned int a = max(v[u].x & 0x7fffffffu, v[u].y & 0x7fffffffu), b = max(v[u].z & 0x7fffffffu, v[u].w & 0x7fffffffu);
+                m = max(m, max(a, b));
+            }
+        }
+        for (; i < n4; i += stride) {
+            const u32x4 v = x4[i];
+            m = max(m, max(max(v.x & 0x7fffffffu, v.y & 0x7fffffffu), max(v.z & 0x7fffffffu, v.w & 0x7fffffffu)));
+        }
+        head = n4 << 2;
     }
-    for (int o = 32; o > 0; o >>= 1) {
-        const unsigned int v = __shfl_xor(m, o);
-        m = v > m ? v : m;
-    }
+    for (int64_t i = head + tid; i < n; i += stride) m = max(m, __float_as_uint(x[i]) & 0x7fffffffu);
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned int)__shfl_xor((int)m, o));
     if ((threadIdx.x & 63) == 0 && m) atomicMax(out_bits, m);
 }
 
+// x /= peak (IEEE division, bit-exact with the reference's elementwise true division, degenerate peaks included: an all-zero
+// bank becomes NaN (0/0) and a NaN anywhere makes the peak -- the largest bit pattern -- and thus everything NaN, exactly like
+// torch's ir_output /= ir_output.abs().max())
 __global__ __launch_bounds__(256) void k_divide(float* __restrict__ x, int64_t n, const unsigned int* __restrict__ peak_bits) {
     const float peak = __uint_as_float(*peak_bits);
-    if (!(peak > 0.0f)) return;
-    const int64_t stride = (int64_t)gridDim.x * 256;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) x[i] = x[i] / peak;   // IEEE division
+    const int64_t stride = (int64_t)gridDim.x * 256, tid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    int64_t head = 0;
+    if (((uintptr_t)x & 15) == 0) {
+        float4* x4 = reinterpret_cast<float4*>(x);
+        const int64_t n4 = n >> 2;
+        int64_t i = tid;
+        for (; i + 3 * stride < n4; i += 4 * stride) {
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = x4[i + u * stride];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                v[u].x = v[u].x / peak; v[u].y = v[u].y / peak; v[u].z = v[u].z / peak; v[u].w = v[u].w / peak;
+                x4[i + u * stride] = v[u];
+            }
+        }
+        for (; i < n4; i += stride) {
+            float4 v = x4[i];
+            v.x = v.x / peak; v.y = v.y / peak; v.z = v.z / peak; v.w = v.w / peak;
+            x4[i] = v;
+        }
+        head = n4 << 2;
+    }
+    for (int64_t i = head + tid; i < n; i += stride) x[i] = x[i] / peak;
 }
 
 // deterministic two-stage float64 sums: partial[a][blockIdx.x] then fixed-order final
@@ -359,6 +428,11 @@ __global__ __launch_bounds__(256) void k_mix_final(const float* __restrict__ noi
     }
 }
 
+__global__ __launch_bounds__(256) void k_div_by(const float* __restrict__ in, float* __restrict__ out, int64_t n, const float* __restrict__ div) {
+    const float r = 1.0f / *div;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) out[i] = in[i] * r;
+}
 __global__ __launch_bounds__(256) void k_scale(const float* __restrict__ in, float* __restrict__ out, int64_t n, float gain) {
     const int64_t stride = (int64_t)gridDim.x * 256;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) out[i] = gain * in[i];
@@ -884,6 +958,7 @@ struct Ctx {
     int os_ablate = 0;      // SS_OS_ABLATE: profiling-only ablation mask (results are WRONG when != 0)
     bool zero_copy = true;  // SS_ZERO_COPY_PLAN=0: upload the plan with a stream-ordered copy instead of device-mapped pinned memory
     bool xcd_order = true;  // SS_XCD_ORDER=0 disables the XCD-aware task order -- tuning knob
+    bool dynq = true;       // SS_DYNQ=0: static task assignment (workgroup b takes tasks b, b + nwg, ...) instead of the per-XCD queues
     // host scratch reused across calls
     std::vector<int64_t> seg_start;
     std::vector<int32_t> bmin, bmax;
@@ -897,15 +972,17 @@ struct Ctx {
     void* gw_cached_dev = nullptr;
     void* kw_cached_dev = nullptr;
     int num_cu = 0;
+    std::mutex mu;          // one lock per device context: entry points are re-entrant per device (one host thread per GPU works)
 };
 
-std::mutex g_mu;
+std::mutex g_mu;            // guards the context map and one-time initialisation only
 std::map<int, Ctx*> g_ctx;
 
 int get_ctx(Ctx** out) {
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return fail(SS_ENODEV, "hipGetDevice failed: %s (no usable GPU; the HIP path has no CPU fallback)", hipGetErrorString(e));
+    std::lock_guard<std::mutex> map_lock(g_mu);
     auto it = g_ctx.find(dev);
     Ctx* c;
     if (it == g_ctx.end()) {
@@ -937,6 +1014,7 @@ int get_ctx(Ctx** out) {
         if (const char* e = getenv("SS_OS_ABLATE")) c->os_ablate = atoi(e);
         if (const char* e = getenv("SS_XCD_ORDER")) c->xcd_order = atoi(e) != 0;
         if (const char* e = getenv("SS_ZERO_COPY_PLAN")) c->zero_copy = atoi(e) != 0;
+        if (const char* e = getenv("SS_DYNQ")) c->dynq = atoi(e) != 0;
         c->inited = true;
     }
     *out = c;
@@ -1029,8 +1107,10 @@ struct Os13AsmArgs {
     void* counter;
     const void* idx;       // explicit schedule (mode 2): interp_index int64[T], interp_weight float[T]
     const void* w;
+    int32_t qgroups;       // dynamic task queues: 0 = static stride-nwg assignment, G = workgroup b pulls from queue b % G (counter[16 * g])
+    int32_t pad_;
 };
-static_assert(sizeof(Os13AsmArgs) == 120, "Os13AsmArgs layout");
+static_assert(sizeof(Os13AsmArgs) == 128, "Os13AsmArgs layout");
 
 // The code object sits next to this shared library (built by sonicsim_amd/build.py); a missing file is an error
 // for the callers that asked for the assembly engine, never a silent fallback.
@@ -1054,7 +1134,8 @@ int load_mod13(Ctx* c) {
 // ---------------------------------------------------------------------------------------------
 // the render engine shared by rows V / I+V / F
 int render(int mode, const float* x, int64_t T, const float* bank, int32_t P, int32_t C, int32_t L,
-           const int64_t* seg_len_host, const int64_t* idx, const float* w, float* y, uint32_t flags, void* stream_) {
+           const int64_t* seg_len_host, const int64_t* idx, const float* w, float* y, uint32_t flags, void* stream_,
+           const float* xdiv = nullptr /* device scalar: render with bank / *xdiv (deferred peak normalisation) */) {
     if (T < 0 || P < 1 || C < 1 || L < 1) return fail(SS_EINVAL, "bad shape: T=%lld P=%d C=%d L=%d", (long long)T, P, C, L);
     if (T == 0) return SS_OK;
     if (!x || !bank || !y) return fail(SS_EINVAL, "NULL data pointer");
@@ -1062,10 +1143,10 @@ int render(int mode, const float* x, int64_t T, const float* bank, int32_t P, in
     if (mode == COEF_SEG && !seg_len_host) return fail(SS_EINVAL, "seg_len is NULL");
     if (mode == COEF_EXPLICIT && (!idx || !w)) return fail(SS_EINVAL, "idx / w is NULL");
     if (T > (int64_t)2000000000LL * 4) return fail(SS_EINVAL, "T too large");
-    std::lock_guard<std::mutex> lk(g_mu);
     Ctx* c;
     int rc = get_ctx(&c);
     if (rc) return rc;
+    std::lock_guard<std::mutex> lk(c->mu);
     hipStream_t stream = (hipStream_t)stream_;
     if ((rc = stream_enter(c, stream))) return rc;
     const bool dev = (flags & SS_FLAG_DEVICE_PTR) != 0;
@@ -1110,6 +1191,13 @@ int render(int mode, const float* x, int64_t T, const float* bank, int32_t P, in
                                                                                                 // the default for long filters
     const bool g12 = g13 || g14 || (use_os && T < ((int64_t)1 << 30) && geom == 12);     // 13/14 share 12's block size, spectra and plan
     if (g14 && (rc = load_mod13(c))) return rc;
+    if (xdiv && !(g13 || g14)) {       // engines without the fused scaling: divide a copy of x (linear in x)
+        if ((rc = ws_ensure(c, WS_W, sizeof(float) * T))) return rc;
+        hipLaunchKernelGGL(k_div_by, dim3(grid_for(T)), dim3(256), 0, stream, dx, (float*)c->ws[WS_W], T, xdiv);
+        HIPCHK(hipGetLastError());
+        dx = (const float*)c->ws[WS_W];
+        xdiv = nullptr;
+    }
     const int BB = g12 ? B12 : B;
     const int JM = g12 ? JMAX12 : JMAX;
     const int M = (int)((T + BB - 1) / BB);
@@ -1197,6 +1285,8 @@ int render(int mode, const float* x, int64_t T, const float* bank, int32_t P, in
         plan_base = (const char*)c->ws[WS_PLAN];
     }
 
+    int qgroups = 0, qinit = 0;
+    const char* trace_env = getenv("SS_TRACE_FILE");      // timeline trace of a code object built with OS13_OPT=trace (tools/)
     RenderParams prm;
     memset(&prm, 0, sizeof(prm));
     prm.x = dx; prm.T = T; prm.bank = dbank; prm.P = P; prm.C = C; prm.L = L; prm.NP = NPart;
@@ -1209,9 +1299,17 @@ int render(int mode, const float* x, int64_t T, const float* bank, int32_t P, in
         prm.Xs = (const c32*)c->ws[WS_XS];
         {
             ProfScope ps(c, stream, 1);
-            if (g13 && (rc = ws_ensure(c, WS_CNT, 64))) return rc;
+            if ((g13 || g14) && (rc = ws_ensure(c, WS_CNT, trace_env ? 512 * 1024 : 8 * 64))) return rc;
+            if (g14 && trace_env) HIPCHK(hipMemsetAsync(c->ws[WS_CNT], 0, 512 * 1024, stream));   // stamps / trace records land behind the queue heads
+            if (g14) {      // dynamic task queues of the assembly kernel: one head per XCD (workgroup b runs on XCD b % 8), preloaded
+                            // with the tasks the workgroups start on
+                const int nwg = (int)(n0 > (size_t)c->num_cu ? (size_t)c->num_cu : n0);
+                qgroups = !c->dynq ? 0 : ((nwg >= 8 && nwg % 8 == 0) ? 8 : 1);
+                qinit = qgroups ? nwg / qgroups : 0;
+            }
             if (g13 || g14) hipLaunchKernelGGL(k_xspec13, dim3(M + 1), dim3(NT13), 0, stream, dx, T, (const c32*)c->consts13, (c32*)c->ws[WS_XS], M,
-                                               dy, (int64_t)C * T, g13 ? (int*)c->ws[WS_CNT] : (int*)nullptr);
+                                               dy, (int64_t)C * T, (g13 || qgroups) ? (int*)c->ws[WS_CNT] : (int*)nullptr, g13 ? 1 : qgroups,
+                                               g13 ? 0 : qinit, xdiv);
             else if (g12) hipLaunchKernelGGL(k_xspec12, dim3(M + 1), dim3(NT12), 0, stream, dx, T, (const c32*)c->consts12, (c32*)c->ws[WS_XS], M,
                                         dy, (int64_t)C * T, (int*)nullptr);
             else hipLaunchKernelGGL(k_xspec, dim3(M + 1), dim3(NT), 0, stream, dx, T, (const c32*)c->consts, (c32*)c->ws[WS_XS], M);
@@ -1234,14 +1332,11 @@ int render(int mode, const float* x, int64_t T, const float* bank, int32_t P, in
             a.inv_seg = plan_base + sizeof(int64_t) * (size_t)P;
             a.y = dy; a.T = T; a.P = P; a.C = C; a.L = L; a.NP = NPart; a.M = M;
             a.ntasks = prm.ntasks; a.mode = mode; a.nwg = (int32_t)nt;
-            a.consts = c->consts14; a.counter = nullptr;
+            a.consts = c->consts14; a.counter = qgroups ? c->ws[WS_CNT] : nullptr;
             a.idx = didx; a.w = dw;
-            const char* trace_file = getenv("SS_TRACE_FILE");      // timeline trace of a code object built with OS13_OPT=trace (tools/)
-            if (trace_file) {
-                if ((rc = ws_ensure(c, WS_CNT, 512 * 1024))) return rc;
-                HIPCHK(hipMemsetAsync(c->ws[WS_CNT], 0, 512 * 1024, stream));
-                a.counter = c->ws[WS_CNT];
-            }
+            a.qgroups = qgroups; a.pad_ = 0;
+            const char* trace_file = trace_env;
+            if (trace_file) a.counter = c->ws[WS_CNT];     // (zeroed ahead of the spectra kernel, which then sets the queue heads)
             size_t asz = sizeof(a);
             void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &asz, HIP_LAUNCH_PARAM_END};
             HIPCHK(hipModuleLaunchKernel(c->fn13, (unsigned)nt, 1, 1, NT13, 1, 1, 0, stream, nullptr, cfg));
@@ -1316,7 +1411,6 @@ int ss_version(void) { return SS_VERSION; }
 const char* ss_last_error(void) { return g_err.c_str(); }
 
 int ss_init(int device) {
-    std::lock_guard<std::mutex> lk(g_mu);
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n <= 0) return fail(SS_ENODEV, "no HIP device available (%s); the HIP path has no CPU fallback", hipGetErrorString(e));
@@ -1359,19 +1453,27 @@ int ss_convolve_moving_seg_f32(const float* x, int64_t T, const float* rirs, int
     return render(COEF_SEG, x, T, rirs, P, C, L, seg_len, nullptr, nullptr, y, flags, stream);
 }
 
+int ss_convolve_moving_seg_div_f32(const float* x, int64_t T, const float* rirs, int32_t P, int32_t C, int32_t L,
+                                   const int64_t* seg_len, const float* divisor, float* y, uint32_t flags, void* stream) {
+    if (!divisor) return fail(SS_EINVAL, "divisor is NULL");
+    if (!(flags & SS_FLAG_DEVICE_PTR)) return fail(SS_EINVAL, "the deferred-normalisation render takes device pointers (SS_FLAG_DEVICE_PTR)");
+    return render(COEF_SEG, x, T, rirs, P, C, L, seg_len, nullptr, nullptr, y, flags, stream, divisor);
+}
+
 int ss_convolve_fixed_f32(const float* x, int64_t T, const float* h, int32_t C, int32_t L, float* y, uint32_t flags,
                           void* stream) {
     return render(COEF_FIXED, x, T, h, 1, C, L, nullptr, nullptr, nullptr, y, flags, stream);
 }
 
-int ss_rir_bank_synth_f32(const SsRirParams* p, float* bank, uint32_t flags, void* stream_) {
+// peak (may be NULL): receives max |bank| -- a DEVICE float when flags has SS_FLAG_DEVICE_PTR (no synchronisation), else a host float
+static int rir_synth(const SsRirParams* p, float* bank, float* peak, uint32_t flags, void* stream_) {
     if (!p || !bank || !p->delay || !p->dgain) return fail(SS_EINVAL, "NULL pointer");
     if (p->P < 1 || p->C < 1 || p->L < 1 || !(p->fs > 0) || !(p->rt60 > 0)) return fail(SS_EINVAL, "bad RIR parameters");
     if (!(p->rho >= 0.0f && p->rho < 1.0f)) return fail(SS_EINVAL, "rho must be in [0,1)");
-    std::lock_guard<std::mutex> lk(g_mu);
     Ctx* c;
     int rc = get_ctx(&c);
     if (rc) return rc;
+    std::lock_guard<std::mutex> lk(c->mu);
     hipStream_t stream = (hipStream_t)stream_;
     if ((rc = stream_enter(c, stream))) return rc;
     const bool dev = (flags & SS_FLAG_DEVICE_PTR) != 0;
@@ -1391,6 +1493,15 @@ int ss_rir_bank_synth_f32(const SsRirParams* p, float* bank, uint32_t flags, voi
         if ((rc = ws_ensure(c, WS_BANK, bytes))) return rc;
         dbank = (float*)c->ws[WS_BANK];
     }
+    unsigned int* dpeak = nullptr;
+    if (peak) {
+        if (dev) dpeak = reinterpret_cast<unsigned int*>(peak);
+        else {
+            if ((rc = ws_ensure(c, WS_SCR, 64))) return rc;
+            dpeak = (unsigned int*)c->ws[WS_SCR];
+        }
+        HIPCHK(hipMemsetAsync(dpeak, 0, sizeof(unsigned int), stream));
+    }
     RirDev d;
     d.P = p->P; d.C = p->C; d.L = p->L;
     d.tail_gain = p->tail_gain; d.rho = p->rho;
@@ -1400,22 +1511,33 @@ int ss_rir_bank_synth_f32(const SsRirParams* p, float* bank, uint32_t flags, voi
     d.delay = (const int32_t*)c->ws[WS_META];
     d.dgain = (const float*)((const char*)c->ws[WS_META] + pc * sizeof(int32_t));
     const int64_t CL = (int64_t)p->C * p->L;
-    hipLaunchKernelGGL(k_rir_synth, dim3((unsigned)((CL + 255) / 256)), dim3(256), 0, stream, d, dbank);
+    const dim3 grid((unsigned)((CL + 255) / 256));
+    if ((uint64_t)pc * (uint64_t)p->L < ((uint64_t)1 << 32)) hipLaunchKernelGGL(k_rir_synth<true>, grid, dim3(256), 0, stream, d, dbank, dpeak);
+    else hipLaunchKernelGGL(k_rir_synth<false>, grid, dim3(256), 0, stream, d, dbank, dpeak);
     HIPCHK(hipGetLastError());
     if (!dev) {
         HIPCHK(hipMemcpyAsync(bank, dbank, bytes, hipMemcpyDeviceToHost, stream));
+        if (peak) HIPCHK(hipMemcpyAsync(peak, dpeak, sizeof(float), hipMemcpyDeviceToHost, stream));
         HIPCHK(hipStreamSynchronize(stream));
     }
     return SS_OK;
 }
 
-int ss_peak_normalize_f32(float* data, int64_t n, float* peak_out, uint32_t flags, void* stream_) {
+int ss_rir_bank_synth_f32(const SsRirParams* p, float* bank, uint32_t flags, void* stream) { return rir_synth(p, bank, nullptr, flags, stream); }
+
+int ss_rir_bank_synth_peak_f32(const SsRirParams* p, float* bank, float* peak, uint32_t flags, void* stream) {
+    if (!peak) return fail(SS_EINVAL, "peak is NULL");
+    return rir_synth(p, bank, peak, flags, stream);
+}
+
+// divisor: the peak already known (device float with SS_FLAG_DEVICE_PTR, else host float); NULL = find it (k_absmax)
+static int normalize(float* data, int64_t n, const float* divisor, float* peak_out, uint32_t flags, void* stream_) {
     if (n < 0 || (n > 0 && !data)) return fail(SS_EINVAL, "bad argument");
     if (n == 0) { if (peak_out) *peak_out = 0.0f; return SS_OK; }
-    std::lock_guard<std::mutex> lk(g_mu);
     Ctx* c;
     int rc = get_ctx(&c);
     if (rc) return rc;
+    std::lock_guard<std::mutex> lk(c->mu);
     hipStream_t stream = (hipStream_t)stream_;
     if ((rc = stream_enter(c, stream))) return rc;
     const bool dev = (flags & SS_FLAG_DEVICE_PTR) != 0;
@@ -1426,10 +1548,16 @@ int ss_peak_normalize_f32(float* data, int64_t n, float* peak_out, uint32_t flag
         d = (float*)c->ws[WS_BANK];
     }
     if ((rc = ws_ensure(c, WS_SCR, 64))) return rc;
-    unsigned int* bits = (unsigned int*)c->ws[WS_SCR];
-    HIPCHK(hipMemsetAsync(bits, 0, sizeof(unsigned int), stream));
-    hipLaunchKernelGGL(k_absmax, dim3(grid_for(n)), dim3(256), 0, stream, (const float*)d, n, bits);
-    hipLaunchKernelGGL(k_divide, dim3(grid_for(n)), dim3(256), 0, stream, d, n, (const unsigned int*)bits);
+    const unsigned int* bits = (const unsigned int*)c->ws[WS_SCR];
+    if (divisor && dev) {
+        bits = reinterpret_cast<const unsigned int*>(divisor);
+    } else if (divisor) {
+        HIPCHK(hipMemcpyAsync(c->ws[WS_SCR], divisor, sizeof(float), hipMemcpyHostToDevice, stream));   // (pageable source: returns after the copy)
+    } else {
+        HIPCHK(hipMemsetAsync(c->ws[WS_SCR], 0, sizeof(unsigned int), stream));
+        hipLaunchKernelGGL(k_absmax, dim3(grid_for((n + 15) >> 4, 4096)), dim3(256), 0, stream, (const float*)d, n, (unsigned int*)c->ws[WS_SCR]);
+    }
+    hipLaunchKernelGGL(k_divide, dim3(grid_for((n + 3) >> 2, 8192)), dim3(256), 0, stream, d, n, bits);
     HIPCHK(hipGetLastError());
     if (peak_out) {
         unsigned int hb = 0;
@@ -1444,12 +1572,21 @@ int ss_peak_normalize_f32(float* data, int64_t n, float* peak_out, uint32_t flag
     return SS_OK;
 }
 
+int ss_peak_normalize_f32(float* data, int64_t n, float* peak_out, uint32_t flags, void* stream) {
+    return normalize(data, n, nullptr, peak_out, flags, stream);
+}
+
+int ss_divide_by_f32(float* data, int64_t n, const float* divisor, uint32_t flags, void* stream) {
+    if (!divisor) return fail(SS_EINVAL, "divisor is NULL");
+    return normalize(data, n, divisor, nullptr, flags, stream);
+}
+
 int ss_rms_db_f32(const float* x, int64_t n, int32_t count, double* out_db, uint32_t flags, void* stream_) {
     if (n <= 0 || count <= 0 || !x || !out_db) return fail(SS_EINVAL, "bad argument");
-    std::lock_guard<std::mutex> lk(g_mu);
     Ctx* c;
     int rc = get_ctx(&c);
     if (rc) return rc;
+    std::lock_guard<std::mutex> lk(c->mu);
     hipStream_t stream = (hipStream_t)stream_;
     if ((rc = stream_enter(c, stream))) return rc;
     const void* dx;
@@ -1474,10 +1611,10 @@ int ss_mix_f32(float* speakers, int32_t S, const float* noises, int32_t N, int64
                float* gains_out, uint32_t flags, void* stream_) {
     if (S < 1 || N < 1 || n <= 0 || !speakers || !noises || !mix || (S > 1 && !sirs)) return fail(SS_EINVAL, "bad argument");
     if (S > 64) return fail(SS_EINVAL, "too many speakers");
-    std::lock_guard<std::mutex> lk(g_mu);
     Ctx* c;
     int rc = get_ctx(&c);
     if (rc) return rc;
+    std::lock_guard<std::mutex> lk(c->mu);
     hipStream_t stream = (hipStream_t)stream_;
     if ((rc = stream_enter(c, stream))) return rc;
     const bool dev = (flags & SS_FLAG_DEVICE_PTR) != 0;
@@ -1540,6 +1677,8 @@ static int kw_setup(const double* coef, KwCoef& k) {
     static double last_coef[12];
     static KwCoef last_k;
     static bool have_last = false;
+    static std::mutex kw_mu;                 // process-wide cache shared by every device context
+    std::lock_guard<std::mutex> kw_lock(kw_mu);
     if (have_last && memcmp(last_coef, coef, sizeof(last_coef)) == 0) { k = last_k; return SS_OK; }
     for (int s = 0; s < 2; ++s) {
         const double a0 = coef[s * 6 + 3];
@@ -1701,10 +1840,10 @@ int ss_kweighted_block_power_f32(const float* audio, int64_t T, int32_t C, const
     if (!audio || T <= 0 || C < 1 || C > 64 || !coef || nblocks < 0 || (nblocks && (!lo || !hi)) || !z_out || !(norm > 0))
         return fail(SS_EINVAL, "bad argument");
     if (nblocks == 0) return SS_OK;
-    std::lock_guard<std::mutex> lk(g_mu);
     Ctx* c;
     int rc = get_ctx(&c);
     if (rc) return rc;
+    std::lock_guard<std::mutex> lk(c->mu);
     hipStream_t stream = (hipStream_t)stream_;
     if ((rc = stream_enter(c, stream))) return rc;
     const void* da;
@@ -1726,10 +1865,10 @@ int ss_lufs_norm_batch_f32(const float* audio, float* out, int64_t T, int32_t C,
         return fail(SS_EINVAL, "bad argument");
     const bool tc = (flags & SS_FLAG_LAYOUT_TC) != 0;
     if (tc && S > 1) return fail(SS_EINVAL, "a batch of stems must be channel-first [S][C][T]");
-    std::lock_guard<std::mutex> lk(g_mu);
     Ctx* c;
     int rc = get_ctx(&c);
     if (rc) return rc;
+    std::lock_guard<std::mutex> lk(c->mu);
     hipStream_t stream = (hipStream_t)stream_;
     if ((rc = stream_enter(c, stream))) return rc;
     const bool dev = (flags & SS_FLAG_DEVICE_PTR) != 0;
@@ -1806,10 +1945,10 @@ int ss_lufs_norm_f32(const float* audio, float* out, int64_t T, int32_t C, const
 
 int ss_scale_f32(const float* in, float* out, int64_t n, float gain, double* sums_out, uint32_t flags, void* stream_) {
     if (n <= 0 || !in || !out) return fail(SS_EINVAL, "bad argument");
-    std::lock_guard<std::mutex> lk(g_mu);
     Ctx* c;
     int rc = get_ctx(&c);
     if (rc) return rc;
+    std::lock_guard<std::mutex> lk(c->mu);
     hipStream_t stream = (hipStream_t)stream_;
     if ((rc = stream_enter(c, stream))) return rc;
     const bool dev = (flags & SS_FLAG_DEVICE_PTR) != 0;
@@ -1849,10 +1988,10 @@ int ss_debug_clk(unsigned long long* out) {
 }
 #endif
 int ss_prof_enable(int on) {
-    std::lock_guard<std::mutex> lk(g_mu);
     Ctx* c;
     int rc = get_ctx(&c);
     if (rc) return rc;
+    std::lock_guard<std::mutex> lk(c->mu);
     HIPCHK(hipDeviceSynchronize());
     for (auto& e : c->evs) { c->ev_pool.push_back(e.a); c->ev_pool.push_back(e.b); }
     c->evs.clear();
@@ -1866,19 +2005,19 @@ int ss_prof_enable(int on) {
 
 int ss_prof_seen(int kind, int64_t* launches) {
     if (!launches || kind < 0 || kind > 3) return fail(SS_EINVAL, "bad argument");
-    std::lock_guard<std::mutex> lk(g_mu);
     Ctx* c;
     int rc = get_ctx(&c);
     if (rc) return rc;
+    std::lock_guard<std::mutex> lk(c->mu);
     *launches = c->prof_seen[kind];
     return SS_OK;
 }
 
 int ss_prof_read(int kind, int64_t* launches, double* total_ms) {
-    std::lock_guard<std::mutex> lk(g_mu);
     Ctx* c;
     int rc = get_ctx(&c);
     if (rc) return rc;
+    std::lock_guard<std::mutex> lk(c->mu);
     HIPCHK(hipDeviceSynchronize());
     int64_t n = 0;
     double tot = 0.0;

@@ -335,17 +335,21 @@ SS_HD void g13_step(Env& env, const Lds13& l, const P& prm, const Task13& tk, St
 // Input spectra on the geometry-13 tables (36 KB of constants instead of 64 KB, the x window is requested before the
 // constants are staged, 16-byte zero fill): window m = x[(m-1)B, (m+1)B) folded to z[n] = (lo - i hi) * exp(-i pi n / 8192),
 // spectrum in the slot layout the render kernels read (c32 index ((r>>1)*512 + tid)*2 + (r&1)).
+// xdiv != nullptr: the spectra are those of x / *xdiv -- the render is linear in x, so this is how a bank's deferred global
+// peak normalisation (SonicSim_audio.py:398, ir_output /= ir_output.abs().max()) reaches the output without a pass over the bank
 template <class Env> SS_HD void xspec13_body(Env& env, const float* x, int64_t T, const c32* consts, c32* Xs, int m, int M,
-                                             float* yzero, int64_t nzero) {
+                                             float* yzero, int64_t nzero, const float* xdiv = nullptr) {
     const int tid = env.tid();
     float lo[8], hi[8];
     if (m < M) {
+        const float xs = xdiv ? 1.0f / *xdiv : 1.0f;
 #pragma unroll
         for (int n1 = 0; n1 < 8; ++n1) {
             const int n = n1 * 512 + tid;
             const int64_t tlo = (int64_t)(m - 1) * B13 + n, thi = (int64_t)m * B13 + n;
             lo[n1] = (tlo >= 0 && tlo < T) ? x[tlo] : 0.0f;
             hi[n1] = (thi < T) ? x[thi] : 0.0f;
+            if (xdiv) { lo[n1] *= xs; hi[n1] *= xs; }
         }
     }
     if (yzero) {   // this workgroup's slice of y (the render kernel accumulates with float atomics onto zero)

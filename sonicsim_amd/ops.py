@@ -54,6 +54,9 @@ def _ptr(a):
 
 
 def _set_device(t):
+    """Make the tensor's device current for the HIP calls that follow (the library picks its per-device context from
+    hipGetDevice).  Callers running several GPUs from one process should wrap their calls in ``torch.cuda.device(i)``; with a
+    single device per process (the torchrun layout) this is a no-op."""
     import torch
     if torch.cuda.current_device() != t.device.index:
         torch.cuda.set_device(t.device)
@@ -115,8 +118,10 @@ def _check_moving_shapes(x, rirs, idx, w):
         raise ValueError("interp_index / interp_weight must have shape (audio_len,)")
 
 
-def convolve_moving_seg(x, rirs, seg_len, path=None, out=None):
-    """Rows I+V fused (SonicSim_moving.py:42-45 + :63-96): seg_len (P-1,) host ints, sum == T."""
+def convolve_moving_seg(x, rirs, seg_len, path=None, out=None, bank_peak=None):
+    """Rows I+V fused (SonicSim_moving.py:42-45 + :63-96): seg_len (P-1,) host ints, sum == T.
+    bank_peak (device tensors only): a one-element float32 device tensor -- render with ``rirs / bank_peak``, i.e. the global
+    peak normalisation of SonicSim_audio.py:398 deferred into the render (``rir_bank_synth(..., return_peak=True)``)."""
     lib = _lib.load()
     flags = PATHS[path]
     seg = np.ascontiguousarray(np.asarray(seg_len).astype(np.int64))
@@ -131,9 +136,17 @@ def convolve_moving_seg(x, rirs, seg_len, path=None, out=None):
         T = x.shape[0]
         _set_device(x)
         y = _out_ct(out, C, T, dev)
+        if bank_peak is not None:
+            if not (_is_dev(bank_peak) and bank_peak.dtype == torch.float32 and bank_peak.numel() == 1 and bank_peak.device == dev):
+                raise ValueError("bank_peak must be a one-element float32 tensor on the device of the bank")
+            _lib.check(lib.ss_convolve_moving_seg_div_f32(_ptr(x), T, _ptr(rirs), P, C, L, _ptr(seg), _ptr(bank_peak), _ptr(y),
+                                                          flags | _lib.FLAG_DEVICE_PTR, _stream_ptr(x)))
+            return y
         _lib.check(lib.ss_convolve_moving_seg_f32(_ptr(x), T, _ptr(rirs), P, C, L, _ptr(seg), _ptr(y),
                                                   flags | _lib.FLAG_DEVICE_PTR, _stream_ptr(x)))
         return y
+    if bank_peak is not None:
+        raise ValueError("bank_peak needs device tensors (the deferred normalisation exists to avoid a pass over a resident bank)")
     x = _np32(x, "x")
     rirs = _np32(rirs, "rirs")
     if x.ndim != 1 or rirs.ndim != 3 or seg.shape != (rirs.shape[0] - 1,):
@@ -173,8 +186,10 @@ def convolve_fixed(x, h, path=None, out=None):
     return y
 
 
-def rir_bank_synth(delay, dgain, L, fs, rt60, seed, tail_gain=0.05, rho=0.9, device=None):
-    """Row R: synthetic bank (P,C,L) float32.  device=None -> NumPy array; else torch tensor on it."""
+def rir_bank_synth(delay, dgain, L, fs, rt60, seed, tail_gain=0.05, rho=0.9, device=None, return_peak=False):
+    """Row R: synthetic bank (P,C,L) float32.  device=None -> NumPy array; else torch tensor on it.
+    return_peak=True -> (bank, peak): max |bank| tracked inside the generating kernel (row G's abs().max() without a second
+    pass) -- a one-element device tensor (no synchronisation) or a Python float for the NumPy form."""
     lib = _lib.load()
     delay = np.ascontiguousarray(np.asarray(delay, dtype=np.int32))
     dgain = np.ascontiguousarray(np.asarray(dgain, dtype=np.float32))
@@ -185,20 +200,32 @@ def rir_bank_synth(delay, dgain, L, fs, rt60, seed, tail_gain=0.05, rho=0.9, dev
                            delay.ctypes.data_as(_lib.c_i32p), dgain.ctypes.data_as(_lib.c_f32p))
     if device is None:
         bank = np.empty((P, C, int(L)), dtype=np.float32)
+        if return_peak:
+            pk = ctypes.c_float(0.0)
+            _lib.check(lib.ss_rir_bank_synth_peak_f32(ctypes.byref(prm), _ptr(bank), ctypes.cast(ctypes.byref(pk), ctypes.c_void_p), 0, None))
+            return bank, float(pk.value)
         _lib.check(lib.ss_rir_bank_synth_f32(ctypes.byref(prm), _ptr(bank), 0, None))
         return bank
     import torch
     dev = torch.device(device)
     bank = torch.empty((P, C, int(L)), dtype=torch.float32, device=dev)
     _set_device(bank)
+    if return_peak:
+        peak = torch.empty(1, dtype=torch.float32, device=dev)
+        _lib.check(lib.ss_rir_bank_synth_peak_f32(ctypes.byref(prm), _ptr(bank), _ptr(peak), _lib.FLAG_DEVICE_PTR, _stream_ptr(bank)))
+        return bank, peak
     _lib.check(lib.ss_rir_bank_synth_f32(ctypes.byref(prm), _ptr(bank), _lib.FLAG_DEVICE_PTR, _stream_ptr(bank)))
     return bank
 
 
-def peak_normalize_(a, want_peak=False):
-    """Row G (SonicSim_audio.py:398): in-place a /= abs(a).max().  Returns the peak if asked."""
+def peak_normalize_(a, want_peak=False, check=False):
+    """Row G (SonicSim_audio.py:398): in-place a /= abs(a).max().  Returns the peak if asked.
+    Degenerate banks behave exactly like the reference's torch expression: an all-zero bank turns into NaN (0/0) and a NaN
+    anywhere makes everything NaN.  ``check=True`` (implies a synchronisation) raises ValueError on such a peak instead of
+    letting it pass silently."""
     lib = _lib.load()
     peak = ctypes.c_float(0.0)
+    want_peak = want_peak or check
     pp = ctypes.byref(peak) if want_peak else None
     if _is_dev(a):
         if not a.is_contiguous() or str(a.dtype) != "torch.float32":
@@ -213,7 +240,30 @@ def peak_normalize_(a, want_peak=False):
         if v.dtype != np.float32 or not v.flags.c_contiguous:
             raise ValueError("peak_normalize_ needs a C-contiguous float32 array")
         _lib.check(lib.ss_peak_normalize_f32(_ptr(v), v.size, pp, 0, None))
+    if check and not (peak.value > 0.0 and np.isfinite(peak.value)):
+        raise ValueError(f"degenerate impulse-response bank: abs().max() = {peak.value} (all zero or not finite)")
     return float(peak.value) if want_peak else None
+
+
+def divide_by_(a, divisor):
+    """a /= divisor with a divisor that is already known (the peak ``rir_bank_synth(..., return_peak=True)`` returned): the one
+    pass that materialises the normalised bank of SonicSim_audio.py:398.  Same IEEE division as ``peak_normalize_``."""
+    lib = _lib.load()
+    if _is_dev(a):
+        import torch
+        if not a.is_contiguous() or a.dtype != torch.float32:
+            raise ValueError("divide_by_ needs a contiguous float32 tensor")
+        if not (_is_dev(divisor) and divisor.dtype == torch.float32 and divisor.numel() == 1 and divisor.device == a.device):
+            raise ValueError("divisor must be a one-element float32 tensor on the same device")
+        _set_device(a)
+        _lib.check(lib.ss_divide_by_f32(_ptr(a), a.numel(), _ptr(divisor), _lib.FLAG_DEVICE_PTR, _stream_ptr(a)))
+        return a
+    v = a.numpy() if _is_torch(a) else a
+    if v.dtype != np.float32 or not v.flags.c_contiguous:
+        raise ValueError("divide_by_ needs a C-contiguous float32 array")
+    d = ctypes.c_float(float(divisor))
+    _lib.check(lib.ss_divide_by_f32(_ptr(v), v.size, ctypes.cast(ctypes.byref(d), ctypes.c_void_p), 0, None))
+    return a
 
 
 def rms_db(x):
@@ -230,9 +280,12 @@ def rms_db(x):
     return float(out.value)
 
 
-def mix(speaker_wav, noise_wav, sirs, snr):
+def mix(speaker_wav, noise_wav, sirs, snr, want_gains=True, out=None):
     """Row M (movingdatamodule.py:105-124).  speaker_wav (S,...), noise_wav (N,...) same trailing shape.
-    Returns (mix, speaker_wav_scaled, gains).  Device tensors are scaled IN PLACE like the reference."""
+    Returns (mix, speaker_wav_scaled, gains).  A contiguous float32 device ``speaker_wav`` is scaled IN PLACE like the reference
+    (:113); any other device input is first copied to that form (the returned tensor is then the scaled copy).
+    want_gains=False skips the D2H copy of the gains and with it the only host synchronisation (gains is None).
+    out (device form): a contiguous float32 tensor shaped like one stem to receive the mix (e.g. a gather slot)."""
     lib = _lib.load()
     sirs = np.ascontiguousarray(np.asarray(sirs, dtype=np.float32).reshape(-1))
     if _is_dev(speaker_wav):
@@ -243,11 +296,14 @@ def mix(speaker_wav, noise_wav, sirs, snr):
         n = spk[0].numel()
         if noi[0].numel() != n or sirs.size < S - 1:
             raise ValueError("shape mismatch between speakers / noises / sirs")
-        out = torch.empty_like(spk[0])
-        gains = np.zeros(S, dtype=np.float32)
+        if out is None:
+            out = torch.empty_like(spk[0])
+        elif not (_is_dev(out) and out.dtype == torch.float32 and out.is_contiguous() and out.shape == spk[0].shape and out.device == spk.device):
+            raise ValueError("out must be a contiguous float32 device tensor shaped like one stem")
+        gains = np.zeros(S, dtype=np.float32) if want_gains else None
         _set_device(spk)
         _lib.check(lib.ss_mix_f32(_ptr(spk), S, _ptr(noi), N, n, sirs.ctypes.data_as(_lib.c_f32p), float(snr), _ptr(out),
-                                  gains.ctypes.data_as(_lib.c_f32p), _lib.FLAG_DEVICE_PTR, _stream_ptr(spk)))
+                                  gains.ctypes.data_as(_lib.c_f32p) if want_gains else None, _lib.FLAG_DEVICE_PTR, _stream_ptr(spk)))
         return out, spk, gains
     spk = np.array(_np32(speaker_wav, "speaker_wav"), copy=True)
     noi = _np32(noise_wav, "noise_wav")

@@ -42,7 +42,8 @@ def shard_range(num_items: int, rank: int, world: int):
 
 
 def gather_to_root(local, dst: int = 0):
-    """Gather equally shaped per-rank tensors to ``dst`` (returns a list on dst, None elsewhere).
+    """Gather per-rank tensors to ``dst`` (returns a list on dst, None elsewhere).  The tensors may differ in their leading
+    dimension or be empty (``shard_range`` gives trailing ranks fewer or no scenes): shapes are exchanged first.
     Implemented as grouped point-to-point send/recv so the root's xGMI links are used in parallel."""
     import torch
     import torch.distributed as dist
@@ -50,15 +51,107 @@ def gather_to_root(local, dst: int = 0):
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return [local]
     rank, world = dist.get_rank(), dist.get_world_size()
+    shp = torch.tensor(list(local.shape), dtype=torch.int64, device=local.device)
+    shapes = [torch.empty_like(shp) for _ in range(world)]
+    dist.all_gather(shapes, shp)                                   # a few bytes; every rank must pass the same ndim
+    shapes = [tuple(int(v) for v in t.tolist()) for t in shapes]
     if rank == dst:
-        bufs = [local if r == dst else torch.empty_like(local) for r in range(world)]
-        ops = [dist.P2POp(dist.irecv, bufs[r], r) for r in range(world) if r != dst]
-        for req in dist.batch_isend_irecv(ops):
-            req.wait()
+        bufs = [local if r == dst else torch.empty(shapes[r], dtype=local.dtype, device=local.device) for r in range(world)]
+        ops = [dist.P2POp(dist.irecv, bufs[r], r) for r in range(world) if r != dst and bufs[r].numel() > 0]
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
         return bufs
-    for req in dist.batch_isend_irecv([dist.P2POp(dist.isend, local, dst)]):
-        req.wait()
+    if local.numel() > 0:
+        for req in dist.batch_isend_irecv([dist.P2POp(dist.isend, local.contiguous(), dst)]):
+            req.wait()
     return None
+
+
+class SceneGather:
+    """Config 4's data path: every rank renders its contiguous block of scenes (``shard_range``) and each finished scene's
+    (C, T) result travels to rank 0 WHILE the next scene renders ("gather scene i while rendering i+1").
+
+    * rank 0 owns ``result[num_scenes, ...]`` and receives every peer's scene straight into its slot (no staging copy); its own
+      scenes are rendered in place there.
+    * the other ranks render into ``depth`` rotating send buffers; ``slot(j)`` hands out the buffer of local step j after making
+      the render stream wait for the transfer that last used it.
+    * ``submit(j)`` enqueues step j's transfers (grouped point-to-point: the root's xGMI links receive in parallel) on a side
+      stream that waits for the render stream, so the render of step j+1 starts immediately.
+    Every rank calls ``slot(j)`` / ``submit(j)`` for j = 0 .. steps()-1 in order (ranks with fewer scenes just take part in the
+    bookkeeping).  With the gloo backend / CPU tensors (tests) the transfers are synchronous and the order is the same."""
+
+    def __init__(self, num_scenes: int, shape, dtype=None, device=None, dst: int = 0, depth: int = 2):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.on = dist.is_initialized() and dist.get_world_size() > 1
+        self.rank = dist.get_rank() if self.on else 0
+        self.world = dist.get_world_size() if self.on else 1
+        self.dst, self.depth, self.num = dst, depth, num_scenes
+        self.ranges = [shard_range(num_scenes, r, self.world) for r in range(self.world)]
+        self.mine = self.ranges[self.rank]
+        dtype = dtype or torch.float32
+        self.cuda = device is not None and torch.device(device).type == "cuda"
+        if self.rank == dst:
+            self.result = torch.empty((num_scenes,) + tuple(shape), dtype=dtype, device=device)
+            self.send = None
+        else:
+            self.result = None
+            self.send = [torch.empty(tuple(shape), dtype=dtype, device=device) for _ in range(depth)]
+        self.side = torch.cuda.Stream(device=device) if self.cuda else None
+        self.done = [None] * depth                       # event of the transfer that last used send buffer b
+
+    def steps(self) -> int:
+        return max(len(r) for r in self.ranges)
+
+    def scene(self, j: int):
+        """global scene index of this rank's local step j (None if this rank has no scene at step j)"""
+        return self.mine[j] if j < len(self.mine) else None
+
+    def slot(self, j: int):
+        """the tensor to render local step j into"""
+        s = self.scene(j)
+        if s is None:
+            return None
+        if self.rank == self.dst:
+            return self.result[s]
+        b = j % self.depth
+        if self.cuda and self.done[b] is not None:
+            self.torch.cuda.current_stream().wait_event(self.done[b])
+        return self.send[b]
+
+    def submit(self, j: int):
+        if not self.on:
+            return
+        dist, torch = self.dist, self.torch
+        ops = []
+        if self.rank == self.dst:
+            for r in range(self.world):
+                if r != self.dst and j < len(self.ranges[r]):
+                    ops.append(dist.P2POp(dist.irecv, self.result[self.ranges[r][j]], r))
+        elif self.scene(j) is not None:
+            ops.append(dist.P2POp(dist.isend, self.send[j % self.depth], self.dst))
+        if not ops:
+            return
+        if self.cuda:
+            self.side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.side):
+                for req in dist.batch_isend_irecv(ops):
+                    req.wait()                           # (stream-ordered for the nccl backend: does not block the host)
+                if self.rank != self.dst:
+                    ev = torch.cuda.Event()
+                    ev.record(self.side)
+                    self.done[j % self.depth] = ev
+        else:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+
+    def finish(self):
+        """all transfers are complete on return of the next synchronisation of the current stream"""
+        if self.cuda:
+            self.torch.cuda.current_stream().wait_stream(self.side)
+        return self.result
 
 
 def barrier_max_seconds(seconds: float, device=None) -> float:

@@ -8,7 +8,13 @@
     1 x  SIR/SNR mix of speakers {1,2} + noise
 
 Everything stays in HBM; only O(P) schedules, O(blocks) loudness gating and scalars touch the host.
-File I/O (torchaudio.save at :102-106, json at :108-136) is out of scope for the timed path.
+File I/O (torchaudio.save at :102-106, json at :108-136) is out of scope for the timed path (``formats.py`` writes it).
+
+Two forms:
+  * ``make_scene_inputs`` + ``render_sonicset_sample``: the banks are resident inputs (what the parity tests compare stage by stage).
+  * ``make_scene_spec`` + ``render_scene``: the banks are PRODUCED inside the scene's work by the RIR provider (K1, with the
+    peak of SonicSim_audio.py:398 tracked by the generator and deferred into the render) -- config 4's unit of work: a rank
+    cannot keep 64 scenes x 3 banks (59 GB) resident, and in SonicSet the provider runs once per scene anyway (SonicSet.py:61-63).
 """
 from __future__ import annotations
 
@@ -25,20 +31,24 @@ LUFS_TARGETS = (-17, -17, -17, -24, -29)          # SonicSet.py:97-101
 @dataclass
 class SceneInputs:
     """Resident inputs of one scene (built once, outside any timed region)."""
-    speakers: list        # 3 x (x (T,), bank (P,C,L), seg_len (P-1,))
+    speakers: list        # 3 x (x (T,), bank (P,C,L), seg_len (P-1,), peak (1,) or None)
     statics: list         # 2 x (x (T,), h (C,L))
     fs: int
 
 
-def make_scene_inputs(device, scene=0, config="cfg2") -> SceneInputs:
+def make_scene_inputs(device, scene=0, config="cfg2", defer_norm=True) -> SceneInputs:
+    """defer_norm=True: the banks stay as generated and their global peak (SonicSim_audio.py:398), tracked by the generator,
+    is applied inside the render (``bank_peak=``); False materialises ``bank / peak`` like generate_rir_combination does."""
     import torch
     spk = []
     for s in range(3):
         sc = synth.make_scene(config, scene=scene * 8 + s)
         seg = synth.scene_segments(sc, scene * 8 + s)
-        bank = ops.rir_bank_synth(sc.delay, sc.dgain, sc.L, sc.fs, sc.rt60, sc.bank_seed, device=device)
-        ops.peak_normalize_(bank)                                   # generate_rir_combination (:398)
-        spk.append((torch.from_numpy(sc.x).to(device), bank, seg))
+        bank, peak = ops.rir_bank_synth(sc.delay, sc.dgain, sc.L, sc.fs, sc.rt60, sc.bank_seed, device=device, return_peak=True)
+        if not defer_norm:
+            ops.divide_by_(bank, peak)                              # generate_rir_combination (:398), one pass
+            peak = None
+        spk.append((torch.from_numpy(sc.x).to(device), bank, seg, peak))
     st = []
     for s in range(2):
         sc = synth.make_scene(config, scene=scene * 8 + 4 + s, P=1)
@@ -47,26 +57,82 @@ def make_scene_inputs(device, scene=0, config="cfg2") -> SceneInputs:
     return SceneInputs(spk, st, sc.fs)
 
 
+def _normalise_and_mix(stack, fs, nstem, sirs, snr, out):
+    # row U for all stems in one device call (targets drawn in stem order like successive reference calls);
+    # (C,T) stems in place of the reference's transposed (T,C)
+    nstack, gains = A.get_lufs_norm_audio_batch(stack, fs, LUFS_TARGETS[:nstem], allow_many_channels=True)
+    normed = [nstack[j] for j in range(nstem)]
+    spk = nstack[:2].clone()                                                     # 2-speaker separation mixture (the mix scales interferers in place, :113)
+    noise = normed[3][None]
+    mix, _ = mixing.mix_sources(spk, noise, np.asarray(sirs, dtype=np.float32), float(snr), out=out)   # row M
+    return mix, normed, gains
+
+
 def render_sonicset_sample(inp: SceneInputs, sirs=(0.0,), snr=15.0, lufs_seed=None):
     """Returns (mix (C,T), stems [5 x (C,T)], gains) -- all torch tensors on the device."""
     if lufs_seed is not None:
         np.random.seed(lufs_seed)
     import torch
-    x0, bank0, _ = inp.speakers[0]
+    x0, bank0 = inp.speakers[0][0], inp.speakers[0][1]
     nstem = len(inp.speakers) + len(inp.statics)
     stack = torch.empty((nstem, bank0.shape[1], x0.shape[-1]), dtype=torch.float32, device=x0.device)   # renders land in one stack
     i = 0
-    for (x, bank, seg) in inp.speakers:                                                        # rows I+V
-        ops.convolve_moving_seg(x, bank, seg, out=stack[i])
+    for (x, bank, seg, peak) in inp.speakers:                                                  # rows (G+)I+V
+        ops.convolve_moving_seg(x, bank, seg, out=stack[i], bank_peak=peak)
         i += 1
     for (x, h) in inp.statics:                                                                 # row F
         ops.convolve_fixed(x, h, out=stack[i])
         i += 1
-    # row U for all stems in one device call (targets drawn in stem order like successive reference calls);
-    # (C,T) stems in place of the reference's transposed (T,C)
-    nstack, gains = A.get_lufs_norm_audio_batch(stack, inp.fs, LUFS_TARGETS[:nstem], allow_many_channels=True)
-    normed = [nstack[j] for j in range(nstem)]
-    spk = nstack[:2].clone()                                                     # 2-speaker separation mixture (the mix scales interferers in place, :113)
-    noise = normed[3][None]
-    mix, _ = mixing.mix_sources(spk, noise, np.asarray(sirs, dtype=np.float32), float(snr))   # row M
-    return mix, normed, gains
+    return _normalise_and_mix(stack, inp.fs, nstem, sirs, snr, None)
+
+
+# ------------------------------------------------------------------------------------------------ config 4's unit of work
+@dataclass
+class SceneSpec:
+    """Host-side description of one scene + its dry signals in HBM (everything the RIR provider and the renders need)."""
+    speakers: list        # 3 x (x (T,) device, delay (P,C) i32, dgain (P,C) f32, seg_len (P-1,), rt60)
+    statics: list         # 2 x (x (T,) device, delay (1,C), dgain (1,C), rt60)
+    T: int
+    C: int
+    L: int
+    fs: int
+
+
+def make_scene_spec(device, scene=0, config="cfg2") -> SceneSpec:
+    """Trajectories, direct-path geometry, segment lengths (host NumPy RNG, like SonicSim_moving.py:32-39) and the five dry
+    signals of one scene.  Host work + H2D: done outside timed regions."""
+    import torch
+    spk, st = [], []
+    for s in range(3):
+        sc = synth.make_scene(config, scene=scene * 8 + s)
+        spk.append((torch.from_numpy(sc.x).to(device), sc.delay, sc.dgain, synth.scene_segments(sc, scene * 8 + s), sc.rt60))
+    for s in range(2):
+        sc = synth.make_scene(config, scene=scene * 8 + 4 + s, P=1)
+        st.append((torch.from_numpy(sc.x).to(device), sc.delay[:1], sc.dgain[:1], sc.rt60))
+    return SceneSpec(spk, st, sc.T, sc.C, sc.L, sc.fs)
+
+
+class SceneRenderer:
+    """Renders SceneSpecs with reused device buffers: one stem stack (5, C, T) and one bank (P, C, L) -- the three speakers of a
+    scene use the bank buffer one after the other on the stream."""
+
+    def __init__(self, spec: SceneSpec, device):
+        import torch
+        self.device = device
+        self.stack = torch.empty((5, spec.C, spec.T), dtype=torch.float32, device=device)
+
+    def render(self, spec: SceneSpec, seed: int, sirs=(0.0,), snr=15.0, out=None):
+        """K1 x 3 (bank + tracked peak) -> moving renders with the normalisation deferred; K1 x 2 -> static renders; loudness of
+        the five stems in one call; mix of speakers {1, 2} + noise into ``out`` (or a fresh tensor).  Returns (mix, gains)."""
+        i = 0
+        for k, (x, delay, dgain, seg, rt60) in enumerate(spec.speakers):
+            bank, peak = ops.rir_bank_synth(delay, dgain, spec.L, spec.fs, rt60, (seed * 8 + k) & 0x7FFFFFFF, device=self.device, return_peak=True)
+            ops.convolve_moving_seg(x, bank, seg, out=self.stack[i], bank_peak=peak)
+            del bank                                                   # back to the caching allocator: the next speaker reuses the block
+            i += 1
+        for k, (x, delay, dgain, rt60) in enumerate(spec.statics):
+            h = ops.rir_bank_synth(delay, dgain, spec.L, spec.fs, rt60, (seed * 8 + 4 + k) & 0x7FFFFFFF, device=self.device)[0]
+            ops.convolve_fixed(x, h, out=self.stack[i])
+            i += 1
+        mix, _, gains = _normalise_and_mix(self.stack, spec.fs, 5, sirs, snr, out)
+        return mix, gains

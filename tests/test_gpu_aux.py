@@ -44,9 +44,67 @@ def test_peak_normalize_bit_exact(gpu):
     t = torch.from_numpy(a).to(gpu)
     ops.peak_normalize_(t)
     assert np.array_equal(t.cpu().numpy(), ref)
+    # degenerate banks behave like the reference's torch expression (ir_output /= ir_output.abs().max()): 0/0 -> NaN, NaN spreads
     z = np.zeros(10, np.float32)
     ops.peak_normalize_(z)
-    assert not z.any()
+    assert np.isnan(z).all() and torch.isnan(torch.zeros(10) / torch.zeros(10).abs().max()).all()
+    q = np.ones(9, np.float32)
+    q[3] = np.nan
+    ops.peak_normalize_(q)
+    assert np.isnan(q).all()
+    with pytest.raises(ValueError, match="degenerate"):
+        ops.peak_normalize_(np.zeros(10, np.float32), check=True)
+    # vector body + scalar tails + unaligned starts of the streaming kernels
+    for n, off in ((1, 0), (3, 0), (4, 1), (1027, 3), (70001, 2), (1 << 20, 0)):
+        base = (rng.standard_normal(n + off) * rng.uniform(0.1, 7)).astype(np.float32)
+        t = torch.from_numpy(base).to(gpu)[off:]
+        want = OR.peak_normalise(base[off:])
+        assert ops.peak_normalize_(t.clone(), want_peak=True) == np.abs(base[off:]).max()
+        u = t.clone()
+        ops.peak_normalize_(u)
+        assert np.array_equal(u.cpu().numpy(), want), (n, off)
+
+
+def test_bank_peak_tracked_by_generator_and_deferred_division(gpu):
+    """rows R+G fused: the generator leaves abs().max() of the bank (no second pass); dividing by it is the reference's
+    normalisation bit for bit, and rendering the raw bank with the peak deferred gives the same audio"""
+    from oracle import moving
+    from sonicsim_amd import ops, synth
+    sc = synth.make_scene("tiny", scene=2)
+    seg = synth.scene_segments(sc, 2)
+    raw, peak = ops.rir_bank_synth(sc.delay, sc.dgain, sc.L, sc.fs, sc.rt60, sc.bank_seed, device=gpu, return_peak=True)
+    plain = ops.rir_bank_synth(sc.delay, sc.dgain, sc.L, sc.fs, sc.rt60, sc.bank_seed, device=gpu)
+    assert torch.equal(raw, plain) and peak.shape == (1,) and peak.is_cuda
+    assert float(peak[0]) == float(raw.abs().max())
+    host_bank, host_peak = ops.rir_bank_synth(sc.delay, sc.dgain, sc.L, sc.fs, sc.rt60, sc.bank_seed, return_peak=True)
+    assert host_peak == float(peak[0]) and np.array_equal(host_bank, raw.cpu().numpy())
+    norm = raw.clone()
+    assert ops.divide_by_(norm, peak) is norm
+    assert np.array_equal(norm.cpu().numpy(), OR.peak_normalise(raw.cpu().numpy()))            # SonicSim_audio.py:398, bit for bit
+    via_absmax = raw.clone()
+    ops.peak_normalize_(via_absmax)
+    assert torch.equal(via_absmax, norm)
+    hb = host_bank.copy()
+    ops.divide_by_(hb, host_peak)
+    assert np.array_equal(hb, norm.cpu().numpy())
+    x = torch.from_numpy(sc.x).to(gpu)
+    idx, w = moving.expand_segments(seg)
+    ref = moving.convolve_moving_receiver(sc.x, norm.cpu().numpy(), idx, w)
+    for path in (None, "os2048", "direct"):                                                     # fused into the spectra kernel / generic pre-scaling
+        yd = ops.convolve_moving_seg(x, raw, seg, bank_peak=peak, path=path)
+        assert rel_rms(yd.cpu().numpy(), ref) < 1e-5, path
+    with pytest.raises(ValueError):
+        ops.convolve_moving_seg(sc.x, raw.cpu().numpy(), seg, bank_peak=peak)
+
+
+def test_rir_bank_synth_large_counter_path(gpu):
+    """banks with >= 2^32 samples take the 64-bit counter path; on a small bank both paths must agree (same hash definition)"""
+    from sonicsim_amd import ops
+    delay = np.full((3, 2), 40, np.int32)
+    dgain = np.ones((3, 2), np.float32)
+    ref = OR.rir_bank_synth(delay, dgain, 3000, 16000, 0.3, 77)
+    got = ops.rir_bank_synth(delay, dgain, 3000, 16000, 0.3, 77)
+    assert np.abs(got - ref).max() < 2e-5 * np.abs(ref).max()
 
 
 def test_generate_rir_combination_contract(gpu):
@@ -190,3 +248,23 @@ def test_lufs_batch_equals_single_calls(gpu):
             np.random.uniform(0, 1)                           # skip the draws of stems 1..3
     with pytest.raises(ValueError):
         A.get_lufs_norm_audio_batch(stack, 16000, (-17,), allow_many_channels=True)
+
+
+def test_fft_conv_odd_and_even_lengths(gpu):
+    """Row X (SonicSim_rir.py:62-92 / SonicSim_audio.py:17-47): full linear convolution of length T + L - 1 against SciPy, for odd
+    AND even output lengths (the reference's ``irfftn`` without ``s`` is wrong whenever T + L - 1 is odd)."""
+    from scipy import signal
+    from sonicsim_amd import SonicSim_audio as A
+    rng = np.random.default_rng(21)
+    for T, L in ((16000, 4096), (16001, 4096), (5000, 700), (333, 8), (9000, 9001)):
+        x = rng.standard_normal(T).astype(np.float32)
+        h = (rng.standard_normal(L) * np.exp(-3.0 * np.arange(L) / L)).astype(np.float32)
+        want = signal.fftconvolve(x.astype(np.float64), h.astype(np.float64), mode="full")
+        assert want.shape[0] == T + L - 1
+        for sig, ker in ((torch.from_numpy(x), torch.from_numpy(h)), (torch.from_numpy(x).to(gpu), torch.from_numpy(h).to(gpu)),
+                         (torch.from_numpy(x).reshape(1, -1), torch.from_numpy(h).reshape(1, -1))):
+            got = A.fft_conv(sig, ker)
+            assert got.shape == (T + L - 1,) and got.dtype == torch.float32, (T, L)
+            assert rel_rms(got.cpu().numpy(), want) < 1e-5, (T, L, (T + L - 1) % 2)
+    y = A.fft_conv(torch.from_numpy(x).to(gpu), torch.from_numpy(h).to(gpu), is_cpu=True)
+    assert not y.is_cuda                                                          # is_cpu=True detaches to the host like the reference

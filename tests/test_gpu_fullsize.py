@@ -1,0 +1,111 @@
+"""Full-size parity at BASELINE.json's sizes: what bench.py times is what is compared.
+
+  cfg2  single moving source, 8 mics, 60 s @ 16 kHz, 200 points, 48000 taps -- the WHOLE output (all T, all channels, default
+        engine) against the pinned oracle's restatement of the reference algorithm (every position convolved, gather, lerp;
+        SonicSim_moving.py:86-94) evaluated 16 positions at a time (bitwise the same as the unchunked form, ~15 s on the box).
+  cfg3  one full SonicSet sample at cfg2 shapes (3 moving + 2 static renders, 5 loudness normalisations, 2-speaker + noise mix),
+        stage by stage against the oracles.
+  cfg5  FOA 120 s @ 48 kHz, 500 points, 96000 taps: 50 segments in five stretches across the render (every row there spans more
+        than four 4096-sample blocks, i.e. takes the split-task path), against the reference algorithm restricted to the
+        positions those segments use (rows of oaconvolve are independent: exactly the reference's arithmetic for those samples).
+Gate: RMS(y - y_ref) / RMS(y_ref) <= 1e-4 per channel and overall (north star)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import moving
+from util import TOL, assert_parity, rel_rms
+
+pytestmark = pytest.mark.gpu
+
+
+def _bank(ops, sc, gpu, normalise=True):
+    bank, peak = ops.rir_bank_synth(sc.delay, sc.dgain, sc.L, sc.fs, sc.rt60, sc.bank_seed, device=gpu, return_peak=True)
+    if normalise:
+        ops.divide_by_(bank, peak)
+    return bank, peak
+
+
+def test_cfg2_whole_output_vs_oracle(gpu):
+    from sonicsim_amd import ops, synth
+    sc = synth.make_scene("cfg2", scene=0)
+    seg = synth.scene_segments(sc, 0)
+    raw, peak = _bank(ops, sc, gpu, normalise=False)
+    bank = raw.clone()
+    ops.divide_by_(bank, peak)                                        # materialised SonicSim_audio.py:398
+    x = torch.from_numpy(sc.x).to(gpu)
+    y = ops.convolve_moving_seg(x, bank, seg)                          # the entry point and engine bench.py times
+    idx, w = moving.expand_segments(seg)
+    ref = moving.convolve_moving_receiver(sc.x, bank.cpu().numpy(), idx, w, p_chunk=16)
+    assert ref.shape == (8, 960000)
+    r = assert_parity(y.cpu().numpy(), ref)
+    scale = float(np.sqrt(np.mean(ref.astype(np.float64) ** 2)))
+    worst = float(np.abs(y.cpu().numpy().astype(np.float64) - ref).max()) / scale
+    print(f"cfg2 whole output: rel RMS {r:.3e}, max abs / RMS {worst:.3e}")
+    assert worst < 50 * TOL
+    # the deferred normalisation (raw bank + peak applied to the dry signal's spectra) renders the same audio
+    yd = ops.convolve_moving_seg(x, raw, seg, bank_peak=peak)
+    assert rel_rms(yd.cpu().numpy(), ref) <= TOL and rel_rms(yd.cpu().numpy(), y.cpu().numpy()) < 2e-6
+    # explicit (idx, w) schedule on the same engine: bit-identical to the implicit ramp at full size
+    y2 = ops.convolve_moving(x, bank, torch.from_numpy(idx).to(gpu), torch.from_numpy(w).to(gpu))
+    assert torch.equal(y, y2)
+
+
+def test_cfg3_full_size_stage_by_stage(gpu):
+    from oracle import loudness as OL
+    from oracle import mix as OM
+    from sonicsim_amd import pipeline
+    inp = pipeline.make_scene_inputs(gpu, scene=1, config="cfg2", defer_norm=True)
+    mix, stems, gains = pipeline.render_sonicset_sample(inp, sirs=(2.0,), snr=12.0, lufs_seed=99)
+    torch.cuda.synchronize()
+    assert mix.shape == (8, 960000) and len(stems) == 5
+    np.random.seed(99)
+    ref_stems = []
+    for (x, bank, seg, peak) in inp.speakers:                       # rows G + I + V: the reference normalises the bank, then renders
+        b = bank.cpu().numpy()
+        b /= np.abs(b).max()                                        # SonicSim_audio.py:398
+        assert np.float32(np.abs(bank.cpu().numpy()).max()) == peak.cpu().numpy()[0]     # the generator's tracked peak IS abs().max()
+        idx, w = moving.expand_segments(seg)
+        ref_stems.append(moving.convolve_moving_receiver(x.cpu().numpy(), b, idx, w, p_chunk=16))
+    for (x, h) in inp.statics:                                       # row F
+        ref_stems.append(moving.convolve_fixed_receiver(x.cpu().numpy(), h.cpu().numpy()))
+    ref_norm = []
+    for i, (y, target) in enumerate(zip(ref_stems, pipeline.LUFS_TARGETS)):      # row U (pyloudnorm restated, float32 in -> float32 path)
+        n, g = OL.get_lufs_norm_audio(np.ascontiguousarray(y.T.astype(np.float32)), 16000, target, allow_many_channels=True)
+        ref_norm.append(np.ascontiguousarray(n.T))
+        r = assert_parity(stems[i].cpu().numpy(), ref_norm[-1])
+        print(f"cfg3 stem {i}: rel RMS {r:.3e}")
+    ref_mix, ref_spk = OM.mix(np.stack(ref_norm[:2]), ref_norm[3][None], np.array([2.0], np.float32), 12.0)     # row M
+    r = assert_parity(mix.cpu().numpy(), ref_mix)
+    print(f"cfg3 mix: rel RMS {r:.3e}")
+
+
+def test_cfg5_fifty_segments(gpu):
+    from sonicsim_amd import ops, synth
+    sc = synth.make_scene("cfg5", scene=1)
+    seg = synth.scene_segments(sc, 1)
+    bank, _ = _bank(ops, sc, gpu)
+    x = torch.from_numpy(sc.x).to(gpu)
+    y = ops.convolve_moving_seg(x, bank, seg)
+    torch.cuda.synchronize()
+    assert y.shape == (4, 5760000)
+    starts = np.concatenate([[0], np.cumsum(seg)])
+    assert ((seg[:-1] + seg[1:]) > 4 * 4096).mean() > 0.7        # most rows (two segments each) span more than four blocks
+    checked = 0
+    for k0 in (0, 97, 230, 371, 489):                            # five stretches of ten consecutive segments
+        k1 = k0 + 10
+        s0, s1 = int(starts[k0]), int(starts[k1])
+        idx, w = moving.expand_segments(seg[k0:k1])
+        xin = sc.x[:s1].copy()
+        xin[:max(0, s0 - sc.L)] = 0                              # causal: input older than L before the stretch cannot matter
+        lo = max(0, s0 - sc.L)
+        full_idx = np.zeros(s1 - lo, dtype=np.int64)
+        full_w = np.zeros(s1 - lo, dtype=np.float32)
+        full_idx[s0 - lo:] = idx
+        full_w[s0 - lo:] = w
+        ref = moving.convolve_moving_receiver(xin[lo:], bank[k0:k1 + 1].cpu().numpy(), full_idx, full_w, p_chunk=4)[:, s0 - lo:]
+        got = y[:, s0:s1].cpu().numpy()
+        r = assert_parity(got, ref)
+        print(f"cfg5 segments {k0}..{k1 - 1}: rel RMS {r:.3e}")
+        checked += int((seg[k0:k1] > 0).sum())
+    assert checked >= 45

@@ -263,12 +263,12 @@ def test_config3_full_sample_pipeline(gpu):
     from oracle import mix as OM
     from sonicsim_amd import pipeline
     cfg = dict(T=80000, P=12, C=4, L=9000, fs=16000, layout="circ")
-    inp = pipeline.make_scene_inputs(gpu, scene=3, config=cfg)
+    inp = pipeline.make_scene_inputs(gpu, scene=3, config=cfg, defer_norm=False)
     mix, stems, gains = pipeline.render_sonicset_sample(inp, sirs=(2.0,), snr=12.0, lufs_seed=99)
     assert mix.shape == (4, 80000) and len(stems) == 5
     np.random.seed(99)
     ref_stems = []
-    for i, (x, bank, seg) in enumerate(inp.speakers):
+    for i, (x, bank, seg, peak) in enumerate(inp.speakers):
         idx, w = moving.expand_segments(seg)
         ref_stems.append(moving.convolve_moving_receiver(x.cpu().numpy(), bank.cpu().numpy(), idx, w))
     for (x, h) in inp.statics:

@@ -25,11 +25,28 @@ def _worker(rank, world, port, q):
     scenes = list(parallel.shard_range(7, r, w))
     local = torch.stack([torch.full((2, 5), float(s)) for s in scenes] + [torch.full((2, 5), -1.0)] * (4 - len(scenes)))
     got = parallel.gather_to_root(local, dst=0)
+    # ragged shards: 3 scenes over 2 ranks -> 2 + 1; and an empty shard (1 scene over 2 ranks)
+    rag = parallel.gather_to_root(torch.stack([torch.full((3,), float(s)) for s in parallel.shard_range(3, r, w)]), dst=0)
+    one = list(parallel.shard_range(1, r, w))
+    emp = parallel.gather_to_root(torch.full((len(one), 3), 7.0), dst=0)
+    # config-4 data path: per-scene gather interleaved with the "renders" (scene s renders to the constant s + 100)
+    sg = parallel.SceneGather(5, (2, 3), dtype=torch.float32, device=None, dst=0)
+    order = []
+    for j in range(sg.steps()):
+        buf = sg.slot(j)
+        if buf is not None:
+            buf.fill_(100.0 + sg.scene(j))
+            order.append(sg.scene(j))
+        sg.submit(j)
+    res = sg.finish()
     tmax = parallel.barrier_max_seconds(1.0 + rank)
     if rank == 0:
+        assert [tuple(t.shape) for t in rag] == [(2, 3), (1, 3)] and rag[1][0, 0] == 2.0
+        assert [tuple(t.shape) for t in emp] == [(1, 3), (0, 3)]
+        assert res.shape == (5, 2, 3) and res[:, 0, 0].tolist() == [100.0, 101.0, 102.0, 103.0, 104.0] and order == [0, 1, 2]
         q.put(([g[:, 0, 0].tolist() for g in got], tmax, scenes))
     else:
-        assert got is None
+        assert got is None and rag is None and emp is None and res is None and order == [3, 4] and sg.steps() == 3
         q.put((None, tmax, scenes))
     import torch.distributed as dist
     dist.barrier()

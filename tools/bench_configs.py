@@ -47,7 +47,7 @@ out["cfg5"] = {"ms_per_render": t * 1e3, "audio_s_per_s": sc.T / sc.fs / t, "alg
 del bank, x
 # config 2 pieces
 inp = pipeline.make_scene_inputs(dev, scene=0, config="cfg2")
-x0, b0, s0 = inp.speakers[0]
+x0, b0, s0, _pk = inp.speakers[0]
 xs, hs = inp.statics[0]
 out["cfg2_moving_ms"] = timeit(lambda: ops.convolve_moving_seg(x0, b0, s0)) * 1e3
 out["cfg2_static_ms"] = timeit(lambda: ops.convolve_fixed(xs, hs)) * 1e3
