@@ -1,5 +1,5 @@
 """GPU box: per-workgroup (start, end) wall-clock stamps of one k_os13_asm launch (code object built with OS13_OPT=wgclk).
-usage: SS_HSACO=sonicsim_amd/lib/var_wgclk.hsaco SS_TRACE_FILE=gpurun_out/wgclk.bin python tools/wgclk.py"""
+usage: SS_HSACO=$PWD/tools/var/wgclk.hsaco SS_TRACE_FILE=gpurun_out/wgclk.bin [SS_DYNQ=0] python tools/wgclk.py"""
 import os, sys, numpy as np, torch
 sys.path.insert(0, ".")
 from sonicsim_amd import ops, synth
@@ -13,7 +13,7 @@ x = torch.from_numpy(sc.x).to(dev)
 for _ in range(4):
     y = ops.convolve_moving_seg(x, bank, seg)
 torch.cuda.synchronize()
-raw = np.fromfile(os.environ["SS_TRACE_FILE"], dtype=np.uint64)[:512].reshape(256, 2).astype(np.int64)
+raw = np.fromfile(os.environ["SS_TRACE_FILE"], dtype=np.uint64)[512:1024].reshape(256, 2).astype(np.int64)   # stamps sit 4 KiB behind the queue heads
 st, en = raw[:, 0], raw[:, 1]
 ok = st > 0
 st, en = st[ok], en[ok]
