@@ -958,7 +958,7 @@ struct Ctx {
     int os_ablate = 0;      // SS_OS_ABLATE: profiling-only ablation mask (results are WRONG when != 0)
     bool zero_copy = true;  // SS_ZERO_COPY_PLAN=0: upload the plan with a stream-ordered copy instead of device-mapped pinned memory
     bool xcd_order = true;  // SS_XCD_ORDER=0 disables the XCD-aware task order -- tuning knob
-    bool dynq = true;       // SS_DYNQ=0: static task assignment (workgroup b takes tasks b, b + nwg, ...) instead of the per-XCD queues
+    bool dynq = false;      // SS_DYNQ=1 (with a code object built with OS13_OPT=dynq): per-XCD dynamic task queues -- experiment, measured slower
     // host scratch reused across calls
     std::vector<int64_t> seg_start;
     std::vector<int32_t> bmin, bmax;
