@@ -131,6 +131,28 @@ int ss_rms_db_f32(const float* x, int64_t n, int32_t count, double* out_db, uint
 int ss_mix_f32(float* speakers, int32_t S, const float* noises, int32_t N, int64_t n, const float* sirs,
                float snr, float* mix, float* gains_out, uint32_t flags, void* stream);
 
+/* ---- row N2: the dataset-side step after the path -- separation/look2hear/datas/movingdatamodule.py:56-126 (MovingTrainDataset
+ *      .__getitem__: mono fold, random crop, -40 dB silence rejection, SIR/SNR mix), twins in enhancement/look2hear/datas/.
+ *      Rendered stems stay in HBM; the Python ``random`` / torch RNG draws stay on the host (their order IS the contract).
+ *      All four take device pointers only (SS_FLAG_DEVICE_PTR). ---------------------------------------------------------------
+ * out[t] = (x[0][t] + ... + x[C-1][t]) / C: ``wav.mean(dim=0)`` (:63, :77), float32 sum in channel order, IEEE division. */
+int ss_mean_channels_f32(const float* x, int32_t C, int64_t T, float* out, uint32_t flags, void* stream);
+/* compute_mch_rms_dB (:29-32) of K crops in one launch: crop k = C rows of n samples, row c at crops[k] + c * chan_stride
+ * (crops: HOST array of K device pointers).  out_db[K] (host) = 10 log10(max(1e-20, mean over all C*n elements)), float64
+ * accumulation.  Synchronises (the -40 dB rejection loop at :84-100 needs the answer before its next random draw). */
+int ss_crop_rms_db_f32(const float* const* crops, int32_t K, int32_t C, int64_t chan_stride, int64_t n, double* out_db,
+                       uint32_t flags, void* stream);
+/* :104-124 for B dataset items in one launch sequence.  speakers[B*S], noises[B*N]: HOST arrays of device pointers to the
+ * crop starts (C rows of n samples, chan_stride apart).  sirs[B*(S-1)], snrs[B] (host) are the drawn values.  Writes
+ * speakers_out[B][S][C][n] (interferers 1..S-1 scaled by 10^(min(E_0 - E_i - sir, 40)/20), the copy the reference returns) and
+ * mix_out[B][C][n] = sum of the scaled speakers + 10^(min(E_speech - E_noise - snr, 40)/20) * sum of the noises, all float32 in
+ * the reference's order of operations; energies in float64.  gains_out[B*S] (host, may be NULL; asking synchronises). */
+int ss_mix_batch_f32(const float* const* speakers, const float* const* noises, int32_t B, int32_t S, int32_t N, int32_t C,
+                     int64_t chan_stride, int64_t n, const float* sirs, const float* snrs, float* speakers_out, float* mix_out,
+                     float* gains_out, uint32_t flags, void* stream);
+/* enhancement/look2hear/datas/movingdatamodule.py:34-48 overlap_audio: out[t] = (x[t-d] + x[t+d]) + x[t] with zero fill. */
+int ss_overlap_audio_f32(const float* x, float* out, int64_t T, int64_t delay_samples, uint32_t flags, void* stream);
+
 /* ---- row U: SonicSim-SonicSet/SonicSim_audio.py:68-81 lufs_norm (pyloudnorm.Meter) -----------
  * BS.1770-4 K-weighted mean-square per gating block:  z[c][j] = sum_{t in [lo_j,hi_j)} k(x_c)[t]^2 / norm
  * where k() is the two-biquad K-weighting cascade (float64 state, coefficients coef[2][6] =

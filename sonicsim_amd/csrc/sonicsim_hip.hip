@@ -438,6 +438,120 @@ __global__ __launch_bounds__(256) void k_scale(const float* __restrict__ in, flo
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) out[i] = gain * in[i];
 }
 
+// ---- row N2: dataset-side crop + silence rejection + batched SIR/SNR mix (separation/look2hear/datas/movingdatamodule.py:81-126)
+// mono[t] = (x[0][t] + x[1][t] + ... ) / C  -- torch's wav.mean(dim=0) (:63, :77): float32 sum in channel order, IEEE division
+__global__ __launch_bounds__(256) void k_mean_channels(const float* __restrict__ x, int C, int64_t T, float* __restrict__ out) {
+    const float fc = (float)C;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < T; t += stride) {
+        float s = x[t];
+        for (int c = 1; c < C; ++c) s += x[(int64_t)c * T + t];
+        out[t] = s / fc;
+    }
+}
+// sum of squares of K crops: crop k = C rows of n samples, row c at ptr[k] + c * chan_stride.  One workgroup per crop
+// (a 4 s mono crop is 256 KB): fixed association -> deterministic.
+__global__ __launch_bounds__(1024) void k_crop_sumsq(const float* const* __restrict__ ptr, int C, int64_t chan_stride, int64_t n,
+                                                     double* __restrict__ out) {
+    __shared__ double sw[16];
+    const float* base = ptr[blockIdx.x];
+    double s = 0.0;
+    for (int c = 0; c < C; ++c) {
+        const float* row = base + (int64_t)c * chan_stride;
+        for (int64_t i = threadIdx.x; i < n; i += 1024) { const double v = (double)row[i]; s += v * v; }
+    }
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int i = 0; i < 16; ++i) t += sw[i];
+        out[blockIdx.x] = t;
+    }
+}
+// batched mix, step 1: interferer gains of item b from the speaker energies (movingdatamodule.py:106-113); one workgroup per item
+__global__ __launch_bounds__(64) void k_bmix_gains1(const double* __restrict__ sumsq /*[B][S]*/, int S, double cnt, const float* __restrict__ sirs /*[B][S-1]*/,
+                                                    float* __restrict__ g /*[B][S+1]*/) {
+    const int b = blockIdx.x, i = threadIdx.x;
+    if (i == 0) g[(int64_t)b * (S + 1)] = 1.0f;
+    if (i >= 1 && i < S) {
+        const double e0 = rms_db_from_sumsq(sumsq[(int64_t)b * S], cnt), ei = rms_db_from_sumsq(sumsq[(int64_t)b * S + i], cnt);
+        double gain = e0 - ei - (double)sirs[(int64_t)b * (S - 1) + i - 1];
+        gain = gain < 40.0 ? gain : 40.0;
+        g[(int64_t)b * (S + 1) + i] = (float)pow(10.0, gain / 20.0);
+    }
+}
+// step 2: scaled speaker crops -> spk_out[b][s][c][i], speech sum -> mix[b][c][i], energies of the speech and noise sums.
+// grid (chunks, B); partial[b][2][chunks]
+__global__ __launch_bounds__(256) void k_bmix_scale_sum(const float* const* __restrict__ sp /*[B][S]*/, const float* const* __restrict__ np /*[B][N]*/, int S, int N,
+                                                        int C, int64_t chan_stride, int64_t n, const float* __restrict__ g, float* __restrict__ spk_out,
+                                                        float* __restrict__ mix, double* __restrict__ partial) {
+    __shared__ double sw[2][4];
+    const int b = blockIdx.y;
+    const int64_t cn = (int64_t)C * n;
+    double e_s = 0.0, e_n = 0.0;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < cn; i += stride) {
+        const int64_t c = i / n, t = i - c * n, src = c * chan_stride + t;
+        float acc = sp[(int64_t)b * S][src];
+        spk_out[((int64_t)b * S) * cn + i] = acc;
+        for (int s2 = 1; s2 < S; ++s2) {
+            const float v = sp[(int64_t)b * S + s2][src] * g[(int64_t)b * (S + 1) + s2];
+            spk_out[((int64_t)b * S + s2) * cn + i] = v;
+            acc += v;
+        }
+        float nz = 0.0f;
+        for (int k = 0; k < N; ++k) nz += np[(int64_t)b * N + k][src];
+        mix[(int64_t)b * cn + i] = acc;
+        e_s += (double)acc * (double)acc;
+        e_n += (double)nz * (double)nz;
+    }
+    for (int o = 32; o > 0; o >>= 1) { e_s += __shfl_xor(e_s, o); e_n += __shfl_xor(e_n, o); }
+    if ((threadIdx.x & 63) == 0) { sw[0][threadIdx.x >> 6] = e_s; sw[1][threadIdx.x >> 6] = e_n; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        partial[((int64_t)b * 2) * gridDim.x + blockIdx.x] = (sw[0][0] + sw[0][1]) + (sw[0][2] + sw[0][3]);
+        partial[((int64_t)b * 2 + 1) * gridDim.x + blockIdx.x] = (sw[1][0] + sw[1][1]) + (sw[1][2] + sw[1][3]);
+    }
+}
+// step 3: noise gain of item b (movingdatamodule.py:118-122); one workgroup of two waves per item
+__global__ __launch_bounds__(128) void k_bmix_gains2(const double* __restrict__ partial, int nb, double cnt, const float* __restrict__ snrs, float* __restrict__ g, int S) {
+    __shared__ double sums[2];
+    const int b = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const double v = wave_final_sum(partial + ((int64_t)b * 2 + w) * nb, nb, lane);
+    if (lane == 0) sums[w] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double gain = rms_db_from_sumsq(sums[0], cnt) - rms_db_from_sumsq(sums[1], cnt) - (double)snrs[b];
+        gain = gain < 40.0 ? gain : 40.0;
+        g[(int64_t)b * (S + 1) + S] = (float)pow(10.0, gain / 20.0);
+    }
+}
+// step 4: mix += g_n * (sum of the noise crops)
+__global__ __launch_bounds__(256) void k_bmix_final(const float* const* __restrict__ np, int N, int C, int64_t chan_stride, int64_t n,
+                                                    const float* __restrict__ g, int S, float* __restrict__ mix) {
+    const int b = blockIdx.y;
+    const int64_t cn = (int64_t)C * n;
+    const float gn = g[(int64_t)b * (S + 1) + S];
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < cn; i += stride) {
+        const int64_t c = i / n, t = i - c * n, src = c * chan_stride + t;
+        float nz = 0.0f;
+        for (int k = 0; k < N; ++k) nz += np[(int64_t)b * N + k][src];
+        const float scaled = nz * gn;
+        mix[(int64_t)b * cn + i] += scaled;
+    }
+}
+// enhancement/look2hear/datas/movingdatamodule.py:34-48 overlap_audio: (x delayed by d) + (x advanced by d) + x, zero filled
+__global__ __launch_bounds__(256) void k_overlap_audio(const float* __restrict__ x, float* __restrict__ out, int64_t T, int64_t d) {
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < T; t += stride) {
+        const float fwd = t >= d ? x[t - d] : 0.0f;
+        const float bwd = t + d < T ? x[t + d] : 0.0f;
+        out[t] = (fwd + bwd) + x[t];
+    }
+}
+
 // ---- K-weighting (row U): two cascaded biquads, transposed direct form II (scipy.signal.lfilter),
 // float64 state.  Chunk-parallel: (1) zero-state run per chunk -> end state, (2) sequential state
 // propagation across chunks with the 4x4 chunk transition matrix, (3) re-run from the true state.
@@ -1941,6 +2055,126 @@ int ss_lufs_norm_f32(const float* audio, float* out, int64_t T, int32_t C, const
                      int32_t nblocks, double block_norm, const double* weights, double target_lufs, double* result, uint32_t flags,
                      void* stream_) {
     return ss_lufs_norm_batch_f32(audio, out, T, C, 1, coef, lo, hi, nblocks, block_norm, weights, &target_lufs, result, flags, stream_);
+}
+
+// upload a small host table through the pinned ring into a workspace slot (stream ordered)
+static int upload_small(Ctx* c, int slot, const void* src, size_t bytes, hipStream_t stream, void** dst) {
+    int rc;
+    Pinned* pin;
+    if ((rc = pinned_acquire(c, bytes, &pin))) return rc;
+    memcpy(pin->host, src, bytes);
+    if ((rc = ws_ensure(c, slot, bytes))) return rc;
+    HIPCHK(hipMemcpyAsync(c->ws[slot], pin->host, bytes, hipMemcpyHostToDevice, stream));
+    HIPCHK(hipEventRecord(pin->ev, stream));
+    pin->pending = true;
+    *dst = c->ws[slot];
+    return SS_OK;
+}
+
+int ss_mean_channels_f32(const float* x, int32_t C, int64_t T, float* out, uint32_t flags, void* stream_) {
+    if (!x || !out || C < 1 || T < 1) return fail(SS_EINVAL, "bad argument");
+    if (!(flags & SS_FLAG_DEVICE_PTR)) return fail(SS_EINVAL, "device pointers only (SS_FLAG_DEVICE_PTR)");
+    Ctx* c;
+    int rc = get_ctx(&c);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(c->mu);
+    hipStream_t stream = (hipStream_t)stream_;
+    if ((rc = stream_enter(c, stream))) return rc;
+    hipLaunchKernelGGL(k_mean_channels, dim3(grid_for(T)), dim3(256), 0, stream, x, C, T, out);
+    HIPCHK(hipGetLastError());
+    return SS_OK;
+}
+
+int ss_crop_rms_db_f32(const float* const* crops, int32_t K, int32_t C, int64_t chan_stride, int64_t n, double* out_db, uint32_t flags,
+                       void* stream_) {
+    if (!crops || !out_db || K < 1 || C < 1 || n < 1) return fail(SS_EINVAL, "bad argument");
+    if (!(flags & SS_FLAG_DEVICE_PTR)) return fail(SS_EINVAL, "device pointers only (SS_FLAG_DEVICE_PTR)");
+    if (K > 4096) return fail(SS_EINVAL, "too many crops in one call");
+    Ctx* c;
+    int rc = get_ctx(&c);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(c->mu);
+    hipStream_t stream = (hipStream_t)stream_;
+    if ((rc = stream_enter(c, stream))) return rc;
+    void* dptr;
+    if ((rc = upload_small(c, WS_META, crops, sizeof(float*) * (size_t)K, stream, &dptr))) return rc;
+    if ((rc = ws_ensure(c, WS_SCR2, sizeof(double) * (size_t)K))) return rc;
+    hipLaunchKernelGGL(k_crop_sumsq, dim3(K), dim3(1024), 0, stream, (const float* const*)dptr, C, chan_stride, n, (double*)c->ws[WS_SCR2]);
+    HIPCHK(hipGetLastError());
+    std::vector<double> ssq((size_t)K);
+    HIPCHK(hipMemcpyAsync(ssq.data(), c->ws[WS_SCR2], sizeof(double) * (size_t)K, hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    const double cnt = (double)C * (double)n;
+    for (int i = 0; i < K; ++i) {
+        const double ms = ssq[(size_t)i] / cnt;
+        out_db[i] = 10.0 * std::log10(ms > 1e-20 ? ms : 1e-20);
+    }
+    return SS_OK;
+}
+
+int ss_mix_batch_f32(const float* const* speakers, const float* const* noises, int32_t B, int32_t S, int32_t N, int32_t C, int64_t chan_stride,
+                     int64_t n, const float* sirs, const float* snrs, float* speakers_out, float* mix_out, float* gains_out, uint32_t flags,
+                     void* stream_) {
+    if (!speakers || !noises || !snrs || !speakers_out || !mix_out || B < 1 || S < 1 || N < 1 || C < 1 || n < 1 || (S > 1 && !sirs))
+        return fail(SS_EINVAL, "bad argument");
+    if (!(flags & SS_FLAG_DEVICE_PTR)) return fail(SS_EINVAL, "device pointers only (SS_FLAG_DEVICE_PTR)");
+    if (S > 64 || B > 65535) return fail(SS_EINVAL, "too many speakers / items");
+    Ctx* c;
+    int rc = get_ctx(&c);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(c->mu);
+    hipStream_t stream = (hipStream_t)stream_;
+    if ((rc = stream_enter(c, stream))) return rc;
+    // one table: [B*S speaker pointers][B*N noise pointers][B*(S-1) sirs][B snrs]
+    const size_t o_np = sizeof(float*) * (size_t)B * S, o_sir = o_np + sizeof(float*) * (size_t)B * N;
+    const size_t o_snr = o_sir + sizeof(float) * (size_t)B * (S > 1 ? S - 1 : 0), bytes = o_snr + sizeof(float) * (size_t)B;
+    std::vector<char> tab(bytes);
+    memcpy(tab.data(), speakers, o_np);
+    memcpy(tab.data() + o_np, noises, o_sir - o_np);
+    if (S > 1) memcpy(tab.data() + o_sir, sirs, o_snr - o_sir);
+    memcpy(tab.data() + o_snr, snrs, sizeof(float) * (size_t)B);
+    void* dtab;
+    if ((rc = upload_small(c, WS_META, tab.data(), bytes, stream, &dtab))) return rc;
+    const float* const* d_sp = (const float* const*)dtab;
+    const float* const* d_np = (const float* const*)((char*)dtab + o_np);
+    const float* d_sir = (const float*)((char*)dtab + o_sir);
+    const float* d_snr = (const float*)((char*)dtab + o_snr);
+    const int64_t cn = (int64_t)C * n;
+    const int nb = grid_for(cn, 64);
+    if ((rc = ws_ensure(c, WS_SCR, sizeof(double) * ((size_t)B * S + (size_t)B * 2 * nb)))) return rc;
+    if ((rc = ws_ensure(c, WS_SCR2, sizeof(float) * (size_t)B * (S + 1)))) return rc;
+    double* d_ssq = (double*)c->ws[WS_SCR];
+    double* d_part = d_ssq + (size_t)B * S;
+    float* d_g = (float*)c->ws[WS_SCR2];
+    hipLaunchKernelGGL(k_crop_sumsq, dim3(B * S), dim3(1024), 0, stream, d_sp, C, chan_stride, n, d_ssq);
+    hipLaunchKernelGGL(k_bmix_gains1, dim3(B), dim3(64), 0, stream, (const double*)d_ssq, S, (double)cn, d_sir, d_g);
+    hipLaunchKernelGGL(k_bmix_scale_sum, dim3(nb, B), dim3(256), 0, stream, d_sp, d_np, S, N, C, chan_stride, n, (const float*)d_g, speakers_out, mix_out,
+                       d_part);
+    hipLaunchKernelGGL(k_bmix_gains2, dim3(B), dim3(128), 0, stream, (const double*)d_part, nb, (double)cn, d_snr, d_g, S);
+    hipLaunchKernelGGL(k_bmix_final, dim3(nb, B), dim3(256), 0, stream, d_np, N, C, chan_stride, n, (const float*)d_g, S, mix_out);
+    HIPCHK(hipGetLastError());
+    if (gains_out) {
+        std::vector<float> g((size_t)B * (S + 1));
+        HIPCHK(hipMemcpyAsync(g.data(), d_g, sizeof(float) * g.size(), hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        for (int b = 0; b < B; ++b)
+            for (int i = 1; i <= S; ++i) gains_out[(size_t)b * S + i - 1] = g[(size_t)b * (S + 1) + i];
+    }
+    return SS_OK;
+}
+
+int ss_overlap_audio_f32(const float* x, float* out, int64_t T, int64_t delay_samples, uint32_t flags, void* stream_) {
+    if (!x || !out || T < 1 || delay_samples < 0 || x == out) return fail(SS_EINVAL, "bad argument");
+    if (!(flags & SS_FLAG_DEVICE_PTR)) return fail(SS_EINVAL, "device pointers only (SS_FLAG_DEVICE_PTR)");
+    Ctx* c;
+    int rc = get_ctx(&c);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(c->mu);
+    hipStream_t stream = (hipStream_t)stream_;
+    if ((rc = stream_enter(c, stream))) return rc;
+    hipLaunchKernelGGL(k_overlap_audio, dim3(grid_for(T)), dim3(256), 0, stream, x, out, T, delay_samples);
+    HIPCHK(hipGetLastError());
+    return SS_OK;
 }
 
 int ss_scale_f32(const float* in, float* out, int64_t n, float gain, double* sums_out, uint32_t flags, void* stream_) {

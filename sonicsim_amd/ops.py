@@ -432,3 +432,89 @@ def prof_read(kind=0):
     ms = ctypes.c_double(0.0)
     _lib.check(_lib.load().ss_prof_read(int(kind), ctypes.byref(n), ctypes.byref(ms)))
     return int(n.value), float(ms.value)
+
+
+# ----------------------------------------------------------------------------- row N2 (dataset-side crop / rejection / batched mix)
+def _ptr_table(ptrs):
+    arr = (ctypes.c_void_p * len(ptrs))(*[ctypes.c_void_p(int(p)) for p in ptrs])
+    return arr
+
+
+def mean_channels(x):
+    """``wav.mean(dim=0)`` of a (C, T) float32 device tensor (movingdatamodule.py:63, :77) -> (T,)."""
+    import torch
+    if not (_is_dev(x) and x.dtype == torch.float32 and x.ndim == 2 and x.is_contiguous()):
+        raise ValueError("mean_channels needs a contiguous float32 (C, T) device tensor")
+    out = torch.empty(x.shape[1], dtype=torch.float32, device=x.device)
+    _set_device(x)
+    _lib.check(_lib.load().ss_mean_channels_f32(_ptr(x), x.shape[0], x.shape[1], _ptr(out), _lib.FLAG_DEVICE_PTR, _stream_ptr(x)))
+    return out
+
+
+def crop_rms_db(stems, starts, n):
+    """compute_mch_rms_dB (movingdatamodule.py:29-32) of crops [start, start + n) of resident stems, all in one launch.
+    stems: list of float32 device tensors, each (T,) or (C, T) contiguous, same shape; starts: list of ints.
+    Returns a float64 array (len(starts), len(stems)).  Synchronises."""
+    t0 = stems[0]
+    C, T = (1, t0.shape[0]) if t0.ndim == 1 else (t0.shape[0], t0.shape[1])
+    ptrs = []
+    for st in starts:
+        if st < 0 or st + n > T:
+            raise ValueError("crop outside the stem")
+        for s in stems:
+            if s.shape != t0.shape or not s.is_contiguous():
+                raise ValueError("stems must be contiguous and share one shape")
+            ptrs.append(s.data_ptr() + 4 * int(st))
+    out = np.zeros(len(ptrs), dtype=np.float64)
+    _set_device(t0)
+    _lib.check(_lib.load().ss_crop_rms_db_f32(_ptr_table(ptrs), len(ptrs), C, T, int(n), out.ctypes.data_as(_lib.c_f64p),
+                                              _lib.FLAG_DEVICE_PTR, _stream_ptr(t0)))
+    return out.reshape(len(starts), len(stems))
+
+
+def mix_batch(speaker_crops, noise_crops, n, sirs, snrs, want_gains=False):
+    """movingdatamodule.py:104-124 for B items in one launch sequence.
+    speaker_crops[b] = list of S (tensor, start) pairs, noise_crops[b] = list of N pairs (tensors (T,) or (C, T), contiguous float32
+    on one device, all with the same C and T); sirs (B, S-1), snrs (B,).
+    Returns (mix (B, [C,] n), speakers (B, S, [C,] n), gains (B, S) or None)."""
+    import torch
+    B = len(speaker_crops)
+    S, N = len(speaker_crops[0]), len(noise_crops[0])
+    t0 = speaker_crops[0][0][0]
+    mono = t0.ndim == 1
+    C, T = (1, t0.shape[0]) if mono else (t0.shape[0], t0.shape[1])
+    sp, npp = [], []
+    for b in range(B):
+        if len(speaker_crops[b]) != S or len(noise_crops[b]) != N:
+            raise ValueError("every item needs the same number of speakers / noises")
+        for lst, dst in ((speaker_crops[b], sp), (noise_crops[b], npp)):
+            for (t, st) in lst:
+                if t.shape != t0.shape or t.dtype != torch.float32 or not t.is_contiguous() or t.device != t0.device:
+                    raise ValueError("stems must be contiguous float32 tensors of one shape on one device")
+                if st < 0 or st + n > T:
+                    raise ValueError("crop outside the stem")
+                dst.append(t.data_ptr() + 4 * int(st))
+    sirs = np.ascontiguousarray(np.asarray(sirs, dtype=np.float32).reshape(B, max(S - 1, 0)))
+    snrs = np.ascontiguousarray(np.asarray(snrs, dtype=np.float32).reshape(B))
+    shape = (n,) if mono else (C, n)
+    spk_out = torch.empty((B, S) + shape, dtype=torch.float32, device=t0.device)
+    mix = torch.empty((B,) + shape, dtype=torch.float32, device=t0.device)
+    gains = np.zeros((B, S), dtype=np.float32) if want_gains else None
+    _set_device(t0)
+    _lib.check(_lib.load().ss_mix_batch_f32(_ptr_table(sp), _ptr_table(npp), B, S, N, C, T, int(n),
+                                            sirs.ctypes.data_as(_lib.c_f32p) if S > 1 else None, snrs.ctypes.data_as(_lib.c_f32p),
+                                            _ptr(spk_out), _ptr(mix), gains.ctypes.data_as(_lib.c_f32p) if want_gains else None,
+                                            _lib.FLAG_DEVICE_PTR, _stream_ptr(t0)))
+    return mix, spk_out, gains
+
+
+def overlap_audio(x, delay_samples):
+    """enhancement/look2hear/datas/movingdatamodule.py:34-48 on a (T,) or (1, T) float32 device tensor."""
+    import torch
+    if not (_is_dev(x) and x.dtype == torch.float32 and x.is_contiguous()):
+        raise ValueError("overlap_audio needs a contiguous float32 device tensor")
+    flat = x.reshape(-1)
+    out = torch.empty_like(flat)
+    _set_device(x)
+    _lib.check(_lib.load().ss_overlap_audio_f32(_ptr(flat), _ptr(out), flat.shape[0], int(delay_samples), _lib.FLAG_DEVICE_PTR, _stream_ptr(x)))
+    return out.reshape(x.shape)
