@@ -153,6 +153,17 @@ int ss_mix_batch_f32(const float* const* speakers, const float* const* noises, i
 /* enhancement/look2hear/datas/movingdatamodule.py:34-48 overlap_audio: out[t] = (x[t-d] + x[t+d]) + x[t] with zero fill. */
 int ss_overlap_audio_f32(const float* x, float* out, int64_t T, int64_t delay_samples, uint32_t flags, void* stream);
 
+/* ---- row N3: the source-assembly step before the path -- torchaudio.transforms.Resample(orig_freq=sr, new_freq=sample_rate)
+ *      at SonicSim-SonicSet/SonicSim_audio.py:249,297 (44.1 / 48 kHz corpora -> 16 kHz).  PARITY UNPINNED (torchaudio is absent): the
+ *      published sinc_interp_hann algorithm, see oracle/resample.py.
+ * x[rows][L] -> out[rows][Lout], Lout = ceil(nnew * L / orig) with orig / nnew already divided by their gcd:
+ *   out[r][f * nnew + p] = sum_{j < ntap} taps[j][p] * x[r][f * orig - width + first[p] + j]   (zeros outside [0, L))
+ * taps[ntap][nnew] (HOST, tap-major) are the non-zero taps of the (2 * width + orig)-tap kernel of phase p, first[nnew] (HOST) the
+ * index of each phase's first kept tap -- built by the host side from the published formula (sonicsim_amd/resample.py).
+ * x / out follow flags bit 0. */
+int ss_resample_f32(const float* x, int32_t rows, int64_t L, int32_t orig, int32_t nnew, int32_t width, const float* taps,
+                    const int32_t* first, int32_t ntap, float* out, int64_t Lout, uint32_t flags, void* stream);
+
 /* ---- row U: SonicSim-SonicSet/SonicSim_audio.py:68-81 lufs_norm (pyloudnorm.Meter) -----------
  * BS.1770-4 K-weighted mean-square per gating block:  z[c][j] = sum_{t in [lo_j,hi_j)} k(x_c)[t]^2 / norm
  * where k() is the two-biquad K-weighting cascade (float64 state, coefficients coef[2][6] =

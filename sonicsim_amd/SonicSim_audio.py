@@ -5,6 +5,8 @@
   get_lufs_norm_audio       SonicSim_audio.py:83-86
   normalize                 SonicSim_audio.py:49-66
   fft_conv                  SonicSim_audio.py:17-47    (row X; see note on the reference's odd-length bug)
+  create_long_audio / create_background_audio / get_random_wav_path(_from_json) / clip_two
+                            SonicSim_audio.py:129-340  (row N3, implemented in assembly.py: same random draws, GPU resampler)
 
 Loudness (row U) -- the O(T*C) work (K-weighting IIR cascade in float64 + per-gating-block mean
 squares) runs on the GPU (``ss_kweighted_block_power_f32``); the O(blocks) gating arithmetic stays
@@ -22,6 +24,8 @@ import typing as T
 import numpy as np
 
 from . import ops
+from .assembly import (clip_two, create_background_audio, create_long_audio, get_random_wav_path,  # noqa: F401  (row N3)
+                       get_random_wav_path_from_json)
 from .SonicSim_rir import render_rir_parallel
 
 G_WEIGHTS = (1.0, 1.0, 1.0, 1.41, 1.41)       # BS.1770 channel weights L R C Ls Rs

@@ -552,6 +552,28 @@ __global__ __launch_bounds__(256) void k_overlap_audio(const float* __restrict__
     }
 }
 
+// ---- row N3: polyphase sinc resampler (torchaudio.transforms.Resample as called at SonicSim_audio.py:249,297).
+// out[row][f * nnew + p] = sum_j taps[j][p] * x[row][f * orig - width + first[p] + j]  (zeros outside [0, L)): the dense
+// (2 width + orig)-tap convolution of the published algorithm restricted to each phase's non-zero taps (the Hann window clamps the
+// rest to exactly 0).  taps is stored tap-major so that the 64 lanes (consecutive phases) read it coalesced; the input window of a
+// frame (orig + 2 width samples) is shared by its nnew outputs and stays in L1.
+__global__ __launch_bounds__(256) void k_resample(const float* __restrict__ x, int64_t L, const float* __restrict__ taps, const int32_t* __restrict__ first,
+                                                  int ntap, int orig, int nnew, int width, float* __restrict__ out, int64_t Lout) {
+    const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (n >= Lout) return;
+    const float* xr = x + (int64_t)blockIdx.y * L;
+    const int64_t f = n / nnew;
+    const int p = (int)(n - f * nnew);
+    const int64_t i0 = f * orig - width + first[p];
+    float acc = 0.0f;
+    for (int j = 0; j < ntap; ++j) {
+        const int64_t i = i0 + j;
+        const float v = (i >= 0 && i < L) ? xr[i] : 0.0f;
+        acc = fmaf(taps[(int64_t)j * nnew + p], v, acc);
+    }
+    out[(int64_t)blockIdx.y * Lout + n] = acc;
+}
+
 // ---- K-weighting (row U): two cascaded biquads, transposed direct form II (scipy.signal.lfilter),
 // float64 state.  Chunk-parallel: (1) zero-state run per chunk -> end state, (2) sequential state
 // propagation across chunks with the 4x4 chunk transition matrix, (3) re-run from the true state.
@@ -1125,7 +1147,9 @@ int get_ctx(Ctx** out) {
         c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         if (const char* e = getenv("SS_OS_GEOM")) c->os_geom = atoi(e);
         if (const char* e = getenv("SS_OS_VARIANT")) c->os_variant = atoi(e);
+#ifdef SS_ABLATE
         if (const char* e = getenv("SS_OS_ABLATE")) c->os_ablate = atoi(e);
+#endif
         if (const char* e = getenv("SS_XCD_ORDER")) c->xcd_order = atoi(e) != 0;
         if (const char* e = getenv("SS_ZERO_COPY_PLAN")) c->zero_copy = atoi(e) != 0;
         if (const char* e = getenv("SS_DYNQ")) c->dynq = atoi(e) != 0;
@@ -1474,6 +1498,7 @@ int render(int mode, const float* x, int64_t T, const float* bank, int32_t P, in
             hipLaunchKernelGGL(k_os13, dim3((unsigned)nt), dim3(NT13), 0, stream, p13);
         }
         else if (!use_os) hipLaunchKernelGGL(k_direct, dim3((unsigned)nt), dim3(NT), 0, stream, prm);
+#ifdef SS_ABLATE      // profiling-only ablation ladder of the HIP engines (results are WRONG when a mask is set): tools/ablate.sh builds with -DSS_ABLATE
         else if (g12 && c->os_ablate == 1) hipLaunchKernelGGL(k_os12<1>, dim3((unsigned)nt), dim3(NT12), 0, stream, prm);
         else if (g12 && c->os_ablate == 2) hipLaunchKernelGGL(k_os12<2>, dim3((unsigned)nt), dim3(NT12), 0, stream, prm);
         else if (g12 && c->os_ablate == 4) hipLaunchKernelGGL(k_os12<4>, dim3((unsigned)nt), dim3(NT12), 0, stream, prm);
@@ -1484,13 +1509,16 @@ int render(int mode, const float* x, int64_t T, const float* bank, int32_t P, in
         else if (g12 && c->os_ablate == 56) hipLaunchKernelGGL(k_os12<56>, dim3((unsigned)nt), dim3(NT12), 0, stream, prm);
         else if (g12 && c->os_ablate == 63) hipLaunchKernelGGL(k_os12<63>, dim3((unsigned)nt), dim3(NT12), 0, stream, prm);
         else if (g12 && c->os_ablate == 7) hipLaunchKernelGGL(k_os12<7>, dim3((unsigned)nt), dim3(NT12), 0, stream, prm);
+#endif
         else if (g12) hipLaunchKernelGGL(k_os12<0>, dim3((unsigned)nt), dim3(NT12), 0, stream, prm);
+#ifdef SS_ABLATE
         else if (c->os_ablate == 1) hipLaunchKernelGGL((k_os<3, 1>), dim3((unsigned)nt), dim3(NT), 0, stream, prm);
         else if (c->os_ablate == 2) hipLaunchKernelGGL((k_os<3, 2>), dim3((unsigned)nt), dim3(NT), 0, stream, prm);
         else if (c->os_ablate == 4) hipLaunchKernelGGL((k_os<3, 4>), dim3((unsigned)nt), dim3(NT), 0, stream, prm);
         else if (c->os_ablate == 3) hipLaunchKernelGGL((k_os<3, 3>), dim3((unsigned)nt), dim3(NT), 0, stream, prm);
         else if (c->os_ablate == 6) hipLaunchKernelGGL((k_os<3, 6>), dim3((unsigned)nt), dim3(NT), 0, stream, prm);
         else if (c->os_ablate == 7) hipLaunchKernelGGL((k_os<3, 7>), dim3((unsigned)nt), dim3(NT), 0, stream, prm);
+#endif
         else if (c->os_variant == 0) hipLaunchKernelGGL(k_os<0>, dim3((unsigned)nt), dim3(NT), 0, stream, prm);
         else if (c->os_variant == 2) hipLaunchKernelGGL(k_os<2>, dim3((unsigned)nt), dim3(NT), 0, stream, prm);
         else hipLaunchKernelGGL(k_os<3>, dim3((unsigned)nt), dim3(NT), 0, stream, prm);
@@ -2174,6 +2202,41 @@ int ss_overlap_audio_f32(const float* x, float* out, int64_t T, int64_t delay_sa
     if ((rc = stream_enter(c, stream))) return rc;
     hipLaunchKernelGGL(k_overlap_audio, dim3(grid_for(T)), dim3(256), 0, stream, x, out, T, delay_samples);
     HIPCHK(hipGetLastError());
+    return SS_OK;
+}
+
+int ss_resample_f32(const float* x, int32_t rows, int64_t L, int32_t orig, int32_t nnew, int32_t width, const float* taps, const int32_t* first,
+                    int32_t ntap, float* out, int64_t Lout, uint32_t flags, void* stream_) {
+    if (!x || !out || !taps || !first || rows < 1 || L < 1 || orig < 1 || nnew < 1 || width < 0 || ntap < 1 || Lout < 1 || rows > 65535)
+        return fail(SS_EINVAL, "bad argument");
+    if (Lout > ((L + orig - 1) / orig + 1) * (int64_t)nnew) return fail(SS_EINVAL, "Lout = %lld is longer than the resampled signal", (long long)Lout);
+    Ctx* c;
+    int rc = get_ctx(&c);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(c->mu);
+    hipStream_t stream = (hipStream_t)stream_;
+    if ((rc = stream_enter(c, stream))) return rc;
+    const bool dev = (flags & SS_FLAG_DEVICE_PTR) != 0;
+    const size_t tb = sizeof(float) * (size_t)ntap * nnew, fb = sizeof(int32_t) * (size_t)nnew;
+    std::vector<char> tab(tb + fb);
+    memcpy(tab.data(), taps, tb);
+    memcpy(tab.data() + tb, first, fb);
+    void* dtab;
+    if ((rc = upload_small(c, WS_META, tab.data(), tb + fb, stream, &dtab))) return rc;
+    const void* dx;
+    if ((rc = stage_in(c, WS_X, x, sizeof(float) * (size_t)rows * L, dev, stream, &dx))) return rc;
+    float* dout = out;
+    if (!dev) {
+        if ((rc = ws_ensure(c, WS_Y, sizeof(float) * (size_t)rows * Lout))) return rc;
+        dout = (float*)c->ws[WS_Y];
+    }
+    hipLaunchKernelGGL(k_resample, dim3((unsigned)((Lout + 255) / 256), rows), dim3(256), 0, stream, (const float*)dx, L, (const float*)dtab,
+                       (const int32_t*)((const char*)dtab + tb), ntap, orig, nnew, width, dout, Lout);
+    HIPCHK(hipGetLastError());
+    if (!dev) {
+        HIPCHK(hipMemcpyAsync(out, dout, sizeof(float) * (size_t)rows * Lout, hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+    }
     return SS_OK;
 }
 

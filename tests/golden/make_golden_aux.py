@@ -6,6 +6,7 @@ packages this image lacks (the same recipe tests/golden/make_golden.py uses for 
 
   SonicSim-SonicSet/SonicSim_audio.py          stubs: torchaudio, pyloudnorm, SonicSim_rir.render_rir_parallel
       -> generate_rir_combination (:342-400: all_pairs, clip_all, stack/reshape, global peak normalise)
+      -> create_long_audio (:231-277), create_background_audio (:279-340), get_random_wav_path(_from_json) (:152-229); Resample stubbed by the oracle's
   separation/look2hear/datas/movingdatamodule.py   stubs: librosa, soundfile, pytorch_lightning, torchaudio.load
       -> compute_mch_rms_dB (:29-32), MovingTrainDataset.__getitem__ (:56-126), MovingTestEvalDataset.__getitem__ (:177-226)
   enhancement/look2hear/datas/movingdatamodule.py  same stubs
@@ -17,6 +18,7 @@ crop start, number of random.randint calls).  This script cannot run on the GPU 
 
     python tests/golden/make_golden_aux.py
 """
+import hashlib
 import importlib.util
 import os
 import random
@@ -31,7 +33,8 @@ import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
-from util import golden_ir, golden_stem  # noqa: E402  (shared seed-regenerable synthetic providers)
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))      # repository root (oracle/)
+from util import golden_clip, golden_ir, golden_stem  # noqa: E402  (shared seed-regenerable synthetic providers)
 
 REF = "/root/reference"
 
@@ -211,9 +214,73 @@ def golden_datamodules():
     np.savez_compressed(os.path.join(HERE, "g10_datamodule.npz"), **out)
 
 
+# ------------------------------------------------------------------------------------------------ row N3 (source assembly)
+def golden_assembly():
+    """create_long_audio / create_background_audio (SonicSim_audio.py:231-340) with their helpers, run UNMODIFIED.  torchaudio.load serves
+    the seed-regenerable clips of tests/util.py::golden_clip; torchaudio.transforms.Resample is the oracle's restatement of the
+    published algorithm (oracle/resample.py -- torchaudio itself is absent, so the resampling arithmetic stays unpinned; what these
+    goldens pin is the selection / layout logic and its consumption of the ``random`` stream)."""
+    import json
+    from oracle import resample as OR
+    root = tempfile.mkdtemp(prefix="ssgold_asm_")
+
+    def load(path):
+        wav, sr = golden_clip(os.path.basename(path))
+        return torch.from_numpy(wav), sr
+
+    class Resample:
+        def __init__(self, orig_freq=16000, new_freq=16000):
+            self.o, self.n = orig_freq, new_freq
+
+        def __call__(self, w):
+            return torch.from_numpy(OR.resample(w.numpy(), self.o, self.n))
+
+    stub("pyloudnorm")
+    ta = stub("torchaudio", load=load)
+    ta.transforms = stub("torchaudio.transforms", Resample=Resample)
+    rir = stub("SonicSim_rir", render_rir_parallel=None)
+    rir.Receiver = rir.Source = rir.Scene = object
+    ref = load_module("ref_SonicSim_audio_asm", os.path.join(REF, "SonicSim-SonicSet", "SonicSim_audio.py"))
+    ref.print = lambda *a, **k: None
+    out = {}
+    cases = {"a": ["u%d.flac" % i for i in range(9)], "b": ["v0.flac", "v1_44k.flac", "v2.flac", "v3_48k.flac", "v4.flac", "v5_44k.flac", "v6.flac"]}
+    for tag, files in cases.items():
+        d = os.path.join(root, "spk_" + tag)
+        os.makedirs(d)
+        for f in files + ["trans.txt"]:
+            open(os.path.join(d, f), "w").close()
+        walk = [os.path.join(r, f) for r, _, fs in os.walk(d) for f in fs if not f.endswith(".txt")]
+        out[f"long_{tag}_walk"] = np.array([os.path.basename(p) for p in walk])
+        random.seed(900 + ord(tag))
+        long_audio, points, names = ref.create_long_audio(d, 45)
+        out[f"long_{tag}_sha"] = hashlib.sha256(long_audio.numpy().tobytes()).hexdigest()
+        out[f"long_{tag}_shape"] = np.array(long_audio.shape)
+        out[f"long_{tag}_points"] = np.array(points, dtype=np.int64).reshape(-1, 2)
+        out[f"long_{tag}_names"] = np.array([os.path.basename(p) for p in names])
+        out[f"long_{tag}_next"] = random.random()
+    bg = {"c": ["n0.wav", "n1_stereo.wav", "n2.wav", "n3_stereo.wav", "n4.wav"], "d": ["m0_44k_stereo.wav", "m1_44k.wav", "m2_44k_stereo.wav", "m3_48k.wav"]}
+    for tag, files in bg.items():
+        lengths = {os.path.join(root, f): int(golden_clip(f)[0].shape[-1]) for f in files}
+        jp = os.path.join(root, f"bg_{tag}.json")
+        json.dump(lengths, open(jp, "w"))
+        out[f"bg_{tag}_files"] = np.array(files)
+        for k, seed in enumerate((31, 32, 33)):
+            random.seed(seed)
+            long_audio, points, names = ref.create_background_audio(jp, 12)
+            out[f"bg_{tag}{k}_sha"] = hashlib.sha256(long_audio.numpy().tobytes()).hexdigest()
+            if (tag, k) == ("d", 0):
+                out["bg_d0_audio"] = long_audio.numpy()          # one full array: the resampled case is compared within a tolerance
+            out[f"bg_{tag}{k}_points"] = np.array(points, dtype=np.int64).reshape(-1, 2)
+            out[f"bg_{tag}{k}_names"] = np.array([os.path.basename(p) for p in names])
+            out[f"bg_{tag}{k}_next"] = random.random()
+    shutil.rmtree(root)
+    np.savez_compressed(os.path.join(HERE, "g11_assembly.npz"), **out)
+
+
 def main():
     golden_rir_combination()
     golden_datamodules()
+    golden_assembly()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))

@@ -1,0 +1,87 @@
+"""The call sequence of SonicSet.py:61-101 (the audio half of ``process_single``), executed verbatim through the alias modules of
+``sonicsim_amd/compat`` under the reference's module names -- what INTEGRATION.md section 1 promises."""
+import os
+import subprocess
+import sys
+import textwrap
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_compat_modules_pass_reference_names_through(tmp_path):
+    """names the package does not accelerate come from the reference's same-named module further down sys.path"""
+    ref = tmp_path / "SonicSim-SonicSet"
+    ref.mkdir()
+    (ref / "SonicSim_audio.py").write_text("def create_long_audio(*a):\n    return 'reference create_long_audio'\n"
+                                           "def tool_only_in_reference():\n    return 42\nSOME_CONSTANT = 7\n")
+    (ref / "SonicSim_rir.py").write_text("import module_that_does_not_exist_here\n")        # like habitat_sim on this image
+    code = textwrap.dedent(f"""
+        import sys
+        sys.path[:0] = [{str(os.path.join(ROOT, 'sonicsim_amd', 'compat'))!r}, {str(ref)!r}]
+        import SonicSim_audio, SonicSim_rir, SonicSim_moving
+        assert SonicSim_audio.tool_only_in_reference() == 42 and SonicSim_audio.SOME_CONSTANT == 7
+        assert SonicSim_audio.create_long_audio.__module__ == 'sonicsim_amd.assembly'      # accelerated names win
+        assert SonicSim_audio.generate_rir_combination.__module__ == 'sonicsim_amd.SonicSim_audio'
+        assert 'ModuleNotFoundError' in SonicSim_rir.REFERENCE_SOURCE and callable(SonicSim_rir.render_ir)
+        assert SonicSim_moving.REFERENCE_SOURCE is None and callable(SonicSim_moving.interpolate_moving_audio)
+        print('ok')
+    """)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr
+
+
+SEQUENCE = '''
+import sys, gc
+sys.path.insert(0, COMPAT)
+import numpy as np, torch
+import SonicSim_rir, SonicSim_audio, SonicSim_moving
+room, sample_rate, channel_type = "17DRP5sb8fy", 16000, "CustomArrayIR"
+mic_array_list = [[0, 0, -0.035], [0.035, 0, 0], [0, 0, 0.035], [-0.035, 0, 0]]          # SonicSet.py:168-174
+rng = np.random.default_rng(0)
+spks_nav_points = [[list(p) for p in np.cumsum(rng.uniform(0.02, 0.2, size=(6, 3)), axis=0) + [1, 1.5, 1]] for _ in range(3)]
+mic_points = [5.0, 1.5, 4.0]
+noise_music_points = [[2.0, 1.5, 6.0], [7.0, 1.5, 2.0]]
+T = 48000
+source_audio = [torch.from_numpy((0.1 * rng.standard_normal((1, T))).astype(np.float32)) for _ in range(3)]
+noise_audio, music_audio = (torch.from_numpy((0.1 * rng.standard_normal((1, T))).astype(np.float32)) for _ in range(2))
+# ---- SonicSet.py:61-68
+ir_outputs = []
+for i in range(len(spks_nav_points)):
+    ir_output = SonicSim_audio.generate_rir_combination(
+            room, spks_nav_points[i], [mic_points], [90], mic_array_list, channel_type
+    )
+    ir_outputs.append(ir_output.cpu())
+    del ir_output
+    gc.collect()
+ir1_list, ir2_list, ir3_list = ir_outputs
+# ---- :77-79
+receiver_audio_1 = SonicSim_moving.interpolate_moving_audio(source_audio[0], ir1_list, spks_nav_points[0])
+receiver_audio_2 = SonicSim_moving.interpolate_moving_audio(source_audio[1], ir2_list, spks_nav_points[1])
+receiver_audio_3 = SonicSim_moving.interpolate_moving_audio(source_audio[2], ir3_list, spks_nav_points[2])
+# ---- :86-94
+rir_noise = SonicSim_rir.create_custom_arrayir(room, noise_music_points[0], mic_points, mic_array=mic_array_list, filename=None, receiver_rotation=90, channel_order=0)
+rir_music = SonicSim_rir.create_custom_arrayir(room, noise_music_points[1], mic_points, mic_array=mic_array_list, filename=None, receiver_rotation=90, channel_order=0)
+rir_noise = torch.from_numpy(SonicSim_moving.convolve_fixed_receiver(noise_audio, rir_noise.cpu()))
+rir_music = torch.from_numpy(SonicSim_moving.convolve_fixed_receiver(music_audio, rir_music.cpu()))
+# ---- :97-101
+receiver_audio_1 = SonicSim_audio.get_lufs_norm_audio(receiver_audio_1.transpose(0,1).numpy(), sample_rate, -17)[0]
+receiver_audio_2 = SonicSim_audio.get_lufs_norm_audio(receiver_audio_2.transpose(0,1).numpy(), sample_rate, -17)[0]
+receiver_audio_3 = SonicSim_audio.get_lufs_norm_audio(receiver_audio_3.transpose(0,1).numpy(), sample_rate, -17)[0]
+rir_noise = SonicSim_audio.get_lufs_norm_audio(rir_noise.transpose(0,1).numpy(), sample_rate, -24)[0]
+rir_music = SonicSim_audio.get_lufs_norm_audio(rir_music.transpose(0,1).numpy(), sample_rate, -29)[0]
+# ---- what :102-106 would hand to torchaudio.save
+for a in (receiver_audio_1, receiver_audio_2, receiver_audio_3, rir_noise, rir_music):
+    w = torch.from_numpy(np.asarray(a)).transpose(0, 1)
+    assert w.shape == (4, T) and w.dtype == torch.float32 and bool(torch.isfinite(w).all()) and float(w.abs().max()) > 0
+assert all(t.shape[:3] == (6, 1, 4) and float(t.abs().max()) == 1.0 for t in ir_outputs)
+print("sequence ok")
+'''
+
+
+@pytest.mark.gpu
+def test_sonicset_lines_61_to_101_through_compat(gpu):
+    code = "COMPAT = %r\n" % os.path.join(ROOT, "sonicsim_amd", "compat") + SEQUENCE
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "sequence ok" in r.stdout, r.stderr[-2000:]

@@ -71,3 +71,17 @@ def golden_ir(case, i, C):
     rng = np.random.default_rng(9000 + 100 * case + i)
     h = rng.standard_normal((C, L)) * np.exp(-np.arange(L) / 200.0)[None, :]
     return h.astype(np.float32)
+
+
+def golden_clip(name):
+    """((C, T) float32, sample_rate) 'file content' of a dry-corpus clip, keyed by its base name: length 1.0-4.5 s, rate 16 kHz unless
+    the name says otherwise ('_44k' -> 44.1 kHz, '_48k' -> 48 kHz), two channels when the name contains 'stereo'."""
+    import zlib
+    rng = np.random.default_rng(zlib.crc32(name.encode()))
+    sr = 44100 if "_44k" in name else (48000 if "_48k" in name else 16000)
+    T = int(rng.uniform(1.0, 4.5) * sr)
+    C = 2 if "stereo" in name else 1
+    t = np.arange(T) / sr
+    tone = np.sin(2 * np.pi * rng.uniform(100, 3000) * t)[None, :] * rng.uniform(0.05, 0.3)
+    x = tone + 0.02 * rng.standard_normal((C, T))
+    return x.astype(np.float32), sr
