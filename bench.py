@@ -139,6 +139,10 @@ def run_cfg2(args, rank, local_rank, world, dev):
     ops.divide_by_(bank, peak)                                                                        # row G, materialised
     x = torch.from_numpy(sc.x).to(dev)
     scratch = torch.empty((sc.C, sc.T), dtype=torch.float32, device=dev)
+    if os.environ.get("BENCH_CALIB"):          # PMC passes (tools/profile.sh): streaming kernels of exactly known byte counts calibrate FETCH_SIZE / WRITE_SIZE
+        calib = bank.clone()
+        ops.peak_normalize_(calib)             # k_absmax reads 4PCL bytes; k_divide reads and writes 4PCL bytes
+        del calib
     torch.cuda.synchronize()
     ge = max(1, args.gather_every)
     do_gather = world > 1 and not args.no_gather

@@ -6,9 +6,11 @@ HBM traffic follows /opt/skills/guides/MI355X_MICROARCH.md (HBM section): FETCH_
 reported in KiB from the L2's memory-side request counters, collected in separate passes; on gfx950
 FETCH_SIZE under-reports coalesced streaming reads by 2x for 16 B/lane accesses and is uncalibrated for
 other widths, so the correction factor is CALIBRATED here on kernels of known byte counts that run in the
-same process with the same access width as the render kernel's RIR stream (4 B/lane coalesced):
+same process (bench.py with BENCH_CALIB=1), both with 16 B/lane coalesced accesses:
   k_absmax  reads  exactly 4*P*C*L bytes (bank)      -> fetch factor
   k_divide  reads and writes exactly 4*P*C*L bytes   -> write factor (and a second fetch point)
+(round 1 calibrated the same two factors with 4 B/lane kernels -- the width of the render kernel's tap stream -- and got the same
+2.00 / 1.00, profiles/r01e.)
 """
 import csv
 import glob
@@ -84,6 +86,7 @@ def main():
             res[k]["write_bytes_raw"] = w_raw
             print(f"  {k}: FETCH raw {f_raw/1e6:.1f} MB -> {f_cor/1e6:.1f} MB   WRITE raw {w_raw/1e6:.1f} MB -> {w_cor/1e6:.1f} MB"
                   f"   total {((f_cor+w_cor)/1e6):.1f} MB per launch")
+    res["_source"] = f"{root}: separate rocprofv3 --pmc passes of `bench.py --steps 3 --warmup 1` (tools/profile.sh), calibrated on k_absmax / k_divide in the same runs"
     json.dump(res, open(os.path.join(root, "pmc_summary.json"), "w"), indent=1)
 
 

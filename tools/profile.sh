@@ -6,8 +6,8 @@ TAG=${1:-r01}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-BENCH="python bench.py --steps 10 --warmup 2 --cpu-positions 0"
-BENCH_PMC="env BENCH_PREWARM_MS=0 python bench.py --steps 3 --warmup 1 --cpu-positions 0"     # counters do not need the sustained state
+BENCH="python bench.py --steps 20 --warmup 5 --cpu-seconds 0"
+BENCH_PMC="env BENCH_PREWARM_MS=0 BENCH_CALIB=1 python bench.py --steps 3 --warmup 1 --cpu-seconds 0"     # counters do not need the sustained state
 echo "== kernel-trace --stats" 
 timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/stats -o stats -f csv -- $BENCH > $OUT/stats.log 2>&1
 tail -2 $OUT/stats.log
