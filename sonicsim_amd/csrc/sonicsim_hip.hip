@@ -154,48 +154,70 @@ __device__ __forceinline__ float box_muller(float u1, float u2) {
 }
 
 // FAST32: the whole bank has fewer than 2^32 samples, so the high counter word is 0 for every sample and the first
-// mixing round of hash32 is one constant per stream (computed once per thread).  peak_bits (may be null): bit pattern of
-// max |bank| over the whole bank (non-negative floats order like their bit patterns) -- row G's abs().max() for free.
-template <bool FAST32>
+// mixing round of hash32 is one constant per stream (computed once per thread).  V consecutive taps per thread (V = 4 when
+// L % 4 == 0: one 16-byte store per position, four independent hash / Box-Muller chains in flight).  peak_bits (may be null):
+// bit pattern of max |bank| over the whole bank (non-negative floats order like their bit patterns) -- row G's abs().max()
+// for free.
+template <bool FAST32, int V>
 __global__ __launch_bounds__(256) void k_rir_synth(RirDev p, float* __restrict__ bank, unsigned int* __restrict__ peak_bits) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * V;
     const int64_t CL = (int64_t)p.C * p.L;
     const bool live = i < CL;
-    const int64_t ii = live ? i : CL - 1;
+    const int64_t ii = live ? i : CL - V;
     const int c = (int)(ii / p.L);
-    const int t = (int)(ii - (int64_t)c * p.L);
-    const float env = (float)exp(-(double)t * p.inv_tau);
-    const float te = p.tail_gain * env;
+    const int t0 = (int)(ii - (int64_t)c * p.L);
+    float te[V], n[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) { te[v] = p.tail_gain * (float)exp(-(double)(t0 + v) * p.inv_tau); n[v] = 0.0f; }
     const uint32_t k1 = p.seed * 0x9E3779B9u + 1u, k2 = p.seed * 0x9E3779B9u + 2u;
     const uint32_t h1c = fmix32(k1), h2c = fmix32(k2);
-    float n = 0.0f, peak = 0.0f;
-    uint64_t ctr = (uint64_t)c * (uint64_t)p.L + (uint64_t)t;
+    float peak = 0.0f;
+    uint64_t ctr = (uint64_t)c * (uint64_t)p.L + (uint64_t)t0;
     float* out = bank + ii;
     const int32_t* dl = p.delay + c;
     const float* dg = p.dgain + c;
     for (int q = 0; q < p.P; ++q) {
-        uint32_t a1, a2;
-        if (FAST32) {
-            a1 = fmix32((uint32_t)ctr ^ h1c);
-            a2 = fmix32((uint32_t)ctr ^ h2c);
-        } else {
-            a1 = fmix32((uint32_t)ctr ^ fmix32((uint32_t)(ctr >> 32) ^ k1));
-            a2 = fmix32((uint32_t)ctr ^ fmix32((uint32_t)(ctr >> 32) ^ k2));
-        }
-        const float g = box_muller(unit24(a1), unit24(a2));
-        n = (q == 0) ? g : (p.rho * n + p.srho * g);
         const int d = dl[(int64_t)q * p.C];
-        float v = (t > d) ? te * n : 0.0f;
-        if (t == d) v += dg[(int64_t)q * p.C];
-        if (live) *out = v;
-        peak = fmaxf(peak, fabsf(v));
+        const float dgain = dg[(int64_t)q * p.C];
+        float val[V];
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            const uint64_t cv = ctr + (uint64_t)v;
+            uint32_t a1, a2;
+            if (FAST32) {
+                a1 = fmix32((uint32_t)cv ^ h1c);
+                a2 = fmix32((uint32_t)cv ^ h2c);
+            } else {
+                a1 = fmix32((uint32_t)cv ^ fmix32((uint32_t)(cv >> 32) ^ k1));
+                a2 = fmix32((uint32_t)cv ^ fmix32((uint32_t)(cv >> 32) ^ k2));
+            }
+            const float g = box_muller(unit24(a1), unit24(a2));
+            n[v] = (q == 0) ? g : (p.rho * n[v] + p.srho * g);
+            const int t = t0 + v;
+            float x = (t > d) ? te[v] * n[v] : 0.0f;
+            if (t == d) x += dgain;
+            val[v] = x;
+            peak = fmaxf(peak, fabsf(x));
+        }
+        if (live) {
+            if (V == 4) *reinterpret_cast<float4*>(out) = make_float4(val[0], val[1], val[2], val[3]);
+            else
+#pragma unroll
+                for (int v = 0; v < V; ++v) out[v] = val[v];
+        }
         out += CL;
         ctr += (uint64_t)CL;
     }
-    if (peak_bits) {
+    if (peak_bits) {      // one atomic per workgroup, and only when it can raise the maximum: atomics on ONE address serialise (~12 ns each)
+        __shared__ float wmax[4];
         if (!live) peak = 0.0f;
         for (int o = 32; o > 0; o >>= 1) peak = fmaxf(peak, __shfl_xor(peak, o));
-        if ((threadIdx.x & 63) == 0 && peak > 0.0f) atomicMax(peak_bits, __float_as_uint(peak));
+        if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = peak;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const float m = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+            if (m > 0.0f && __float_as_uint(m) > __hip_atomic_load(peak_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(peak_bits, __float_as_uint(m));
+        }
     }
 }
 
@@ -228,8 +250,16 @@ __global__ __launch_bounds__(256) void k_absmax(const float* __restrict__ x, int
         head = n4 << 2;
     }
     for (int64_t i = head + tid; i < n; i += stride) m = max(m, __float_as_uint(x[i]) & 0x7fffffffu);
+    // one atomic per workgroup, and only when it can raise the maximum: atomics on ONE address serialise (~12 ns each; the
+    // first version's 16 K wave-level atomics cost more than streaming the 307 MB)
+    __shared__ unsigned int wmax[4];
     for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned int)__shfl_xor((int)m, o));
-    if ((threadIdx.x & 63) == 0 && m) atomicMax(out_bits, m);
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3]));
+        if (m > __hip_atomic_load(out_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(out_bits, m);
+    }
 }
 
 // x /= peak (IEEE division, bit-exact with the reference's elementwise true division, degenerate peaks included: an all-zero
@@ -1653,9 +1683,13 @@ static int rir_synth(const SsRirParams* p, float* bank, float* peak, uint32_t fl
     d.delay = (const int32_t*)c->ws[WS_META];
     d.dgain = (const float*)((const char*)c->ws[WS_META] + pc * sizeof(int32_t));
     const int64_t CL = (int64_t)p->C * p->L;
-    const dim3 grid((unsigned)((CL + 255) / 256));
-    if ((uint64_t)pc * (uint64_t)p->L < ((uint64_t)1 << 32)) hipLaunchKernelGGL(k_rir_synth<true>, grid, dim3(256), 0, stream, d, dbank, dpeak);
-    else hipLaunchKernelGGL(k_rir_synth<false>, grid, dim3(256), 0, stream, d, dbank, dpeak);
+    const bool fast32 = (uint64_t)pc * (uint64_t)p->L < ((uint64_t)1 << 32);
+    const bool vec4 = p->L % 4 == 0 && ((uintptr_t)dbank & 15) == 0;
+    const dim3 grid((unsigned)((CL / (vec4 ? 4 : 1) + 255) / 256));
+    if (fast32 && vec4) hipLaunchKernelGGL((k_rir_synth<true, 4>), grid, dim3(256), 0, stream, d, dbank, dpeak);
+    else if (fast32) hipLaunchKernelGGL((k_rir_synth<true, 1>), grid, dim3(256), 0, stream, d, dbank, dpeak);
+    else if (vec4) hipLaunchKernelGGL((k_rir_synth<false, 4>), grid, dim3(256), 0, stream, d, dbank, dpeak);
+    else hipLaunchKernelGGL((k_rir_synth<false, 1>), grid, dim3(256), 0, stream, d, dbank, dpeak);
     HIPCHK(hipGetLastError());
     if (!dev) {
         HIPCHK(hipMemcpyAsync(bank, dbank, bytes, hipMemcpyDeviceToHost, stream));
@@ -1697,7 +1731,7 @@ static int normalize(float* data, int64_t n, const float* divisor, float* peak_o
         HIPCHK(hipMemcpyAsync(c->ws[WS_SCR], divisor, sizeof(float), hipMemcpyHostToDevice, stream));   // (pageable source: returns after the copy)
     } else {
         HIPCHK(hipMemsetAsync(c->ws[WS_SCR], 0, sizeof(unsigned int), stream));
-        hipLaunchKernelGGL(k_absmax, dim3(grid_for((n + 15) >> 4, 4096)), dim3(256), 0, stream, (const float*)d, n, (unsigned int*)c->ws[WS_SCR]);
+        hipLaunchKernelGGL(k_absmax, dim3(grid_for((n + 31) >> 5, 2048)), dim3(256), 0, stream, (const float*)d, n, (unsigned int*)c->ws[WS_SCR]);
     }
     hipLaunchKernelGGL(k_divide, dim3(grid_for((n + 3) >> 2, 8192)), dim3(256), 0, stream, d, n, bits);
     HIPCHK(hipGetLastError());

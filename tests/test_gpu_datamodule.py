@@ -114,7 +114,11 @@ def test_crop_energy_and_mono_fold(gpu):
         a = (rng.standard_normal((C, 50000)) * 0.03).astype(np.float32)
         t = torch.from_numpy(a).to(gpu)
         m = ops.mean_channels(t)
-        assert np.array_equal(m.cpu().numpy(), torch.from_numpy(a).mean(dim=0).numpy()), C      # torch's wav.mean(dim=0), bit for bit
+        want = torch.from_numpy(a).mean(dim=0).numpy()
+        if C <= 4:      # torch adds the channels in order for up to four rows (the 1/2/4-mic stems of SonicSet): bit for bit
+            assert np.array_equal(m.cpu().numpy(), want), C
+        else:           # beyond that torch's CPU reduction re-associates the float32 adds for long signals: round-off only
+            assert np.abs(m.cpu().numpy() - want).max() <= 2e-7 * np.abs(want).max() + 1e-9, C
         db = ops.crop_rms_db([t, t * 0.5], [0, 1234, 50000 - 4000], 4000)
         for k, st in enumerate((0, 1234, 50000 - 4000)):
             assert abs(db[k, 0] - float(OM.compute_mch_rms_dB(a[:, st:st + 4000]))) < 1e-4
