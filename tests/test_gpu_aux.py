@@ -102,7 +102,7 @@ def test_rir_bank_synth_large_counter_path(gpu):
     from sonicsim_amd import ops
     delay = np.full((3, 2), 40, np.int32)
     dgain = np.ones((3, 2), np.float32)
-    for L in (3000, 3001, 7):                         # four taps per thread (16-byte stores) / one tap per thread
+    for L in (3000, 3001, 45):                        # four taps per thread (16-byte stores) / one tap per thread
         ref = OR.rir_bank_synth(delay, dgain, L, 16000, 0.3, 77)
         got, peak = ops.rir_bank_synth(delay, dgain, L, 16000, 0.3, 77, return_peak=True)
         assert np.abs(got - ref).max() < 2e-5 * np.abs(ref).max(), L
