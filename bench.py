@@ -226,7 +226,8 @@ def run_cfg2(args, rank, local_rank, world, dev):
         except Exception:
             traffic = None
     out = {
-        "metric": "rendered-audio-sec/sec (8-mic, 200-pt trajectory, 16 kHz)",
+        "metric": "rendered-audio-sec/sec (8-mic, 200-pt trajectory, 16 kHz)" if args.config == "cfg2" else
+                  f"rendered-audio-sec/sec ({sc.C}-ch, {sc.P}-pt trajectory, {sc.fs // 1000} kHz)",
         "value": value,
         "unit": "rendered-audio-sec/sec",
         "n_gpus": world,

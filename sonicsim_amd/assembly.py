@@ -9,7 +9,7 @@ as ``SonicSim-SonicSet/SonicSim_audio.py``:
   create_background_audio        :279-340   background clips (stereo -> mono) with trailing silences, the last one cropped
 
 Differences, all outside the arithmetic: files are read by ``loader(path) -> (waveform (C, T) float32, sample_rate)`` (default:
-``wavio.load``, WAV only -- the reference reads FLAC through torchaudio, pass a loader for that) and off-rate material is
+``wavio.load`` for WAV, ``torchaudio.load`` for anything else when torchaudio is installed, as in the reference's environment) and off-rate material is
 resampled by the GPU resampler (``resample.Resample``; the reference builds ``torchaudio.transforms.Resample(sr, sample_rate)``).
 The layout itself is host glue on CPU tensors, exactly like the reference's."""
 from __future__ import annotations
@@ -25,9 +25,15 @@ from . import wavio
 
 
 def _default_loader(path):
-    if not str(path).lower().endswith(".wav"):
-        raise RuntimeError(f"{path}: only WAV is read natively; pass loader=(path -> (waveform (C, T) float32, sample_rate)) for other formats")
-    return wavio.load(path)
+    """WAV natively; anything else (LibriSpeech is FLAC) through torchaudio when the reference's environment provides it."""
+    if str(path).lower().endswith(".wav"):
+        return wavio.load(path)
+    try:
+        import torchaudio
+    except ImportError:
+        raise RuntimeError(f"{path}: only WAV is read natively and torchaudio is not installed; pass "
+                           "loader=(path -> (waveform (C, T) float32, sample_rate))") from None
+    return torchaudio.load(path)
 
 
 def _load_at_rate(path, sample_rate, loader):

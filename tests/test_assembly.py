@@ -79,7 +79,7 @@ def test_random_wav_path_helpers(tmp_path, monkeypatch):
     assert 1 <= len(picked) <= 3 and len(set(picked)) == len(picked)
     a, b = assembly.clip_two(torch.zeros(2, 10), torch.zeros(2, 7))
     assert a.shape == b.shape == (2, 7)
-    with pytest.raises(RuntimeError, match="only WAV"):
+    with pytest.raises(RuntimeError, match="only WAV"):          # torchaudio is not part of this image
         assembly._default_loader("x.flac")
 
 
