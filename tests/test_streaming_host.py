@@ -24,9 +24,10 @@ def test_ranges_shards_and_streaming_match_the_whole_render(oracle_ops):
     bank = (rng.standard_normal((sc.P, sc.C, sc.L)) * np.exp(-np.arange(sc.L) / 1500)).astype(np.float32)
     ref = moving.convolve_moving_receiver(sc.x, bank, *moving.expand_segments(seg))
     starts = np.concatenate([[0], np.cumsum(seg)])
+    scale = float(np.sqrt(np.mean(ref.astype(np.float64) ** 2)))
     for (t0, t1) in ((0, sc.T), (int(starts[3]), int(starts[7])), (1234, 45678), (int(starts[5]), int(starts[5]) + 50), (sc.T - 9, sc.T), (0, 1)):
         y = streaming.render_range(sc.x, bank, seg, t0, t1)
-        assert y.shape == (sc.C, t1 - t0) and moving.rel_rms(y, ref[:, t0:t1]) < 2e-6, (t0, t1)
+        assert y.shape == (sc.C, t1 - t0) and np.abs(y - ref[:, t0:t1]).max() < 2e-5 * scale, (t0, t1)
     for world in (1, 2, 3, 5):
         cuts = streaming.shard_cuts(seg, world)
         assert cuts[0] == 0 and cuts[-1] == sc.T and len(cuts) == world + 1 and all(c in set(starts) for c in cuts)
