@@ -223,7 +223,8 @@ __global__ __launch_bounds__(256) void k_rir_synth(RirDev p, float* __restrict__
 
 // ---------------------------------------------------------------------------------------------
 // reductions / elementwise (rows G, M, U)
-// 16-byte loads, 8 independent loads in flight per thread: a pure streaming max must run at the copy ceiling
+// 16-byte loads, 8 independent loads in flight per thread, at most 512 workgroups (grid sweep in profiles/r02f: 512 -> 41 us, 2048 -> 53 us,
+// 8192 -> 60 us for 307 MB): a pure streaming max must run at the copy ceiling
 __global__ __launch_bounds__(256) void k_absmax(const float* __restrict__ x, int64_t n, unsigned int* __restrict__ out_bits) {
     unsigned int m = 0;
     const int64_t stride = (int64_t)gridDim.x * 256, tid = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -1731,7 +1732,7 @@ static int normalize(float* data, int64_t n, const float* divisor, float* peak_o
         HIPCHK(hipMemcpyAsync(c->ws[WS_SCR], divisor, sizeof(float), hipMemcpyHostToDevice, stream));   // (pageable source: returns after the copy)
     } else {
         HIPCHK(hipMemsetAsync(c->ws[WS_SCR], 0, sizeof(unsigned int), stream));
-        hipLaunchKernelGGL(k_absmax, dim3(grid_for((n + 31) >> 5, 2048)), dim3(256), 0, stream, (const float*)d, n, (unsigned int*)c->ws[WS_SCR]);
+        hipLaunchKernelGGL(k_absmax, dim3(grid_for((n + 31) >> 5, 512)), dim3(256), 0, stream, (const float*)d, n, (unsigned int*)c->ws[WS_SCR]);
     }
     hipLaunchKernelGGL(k_divide, dim3(grid_for((n + 3) >> 2, 8192)), dim3(256), 0, stream, d, n, bits);
     HIPCHK(hipGetLastError());
