@@ -290,6 +290,9 @@ def run_scenes(args, rank, local_rank, world, dev):
     gather = args.config == "cfg4" and not args.no_gather
     np.random.seed(7000 + rank)
     torch.manual_seed(7000 + rank)
+    import gc
+    gc.collect()
+    gc.freeze()          # one generation-2 collection (40-60 ms with torch imported) would otherwise land inside the timed scenes (profiles/r02p)
 
     def run(k, sg, base):
         for j in range(k):

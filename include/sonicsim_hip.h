@@ -42,6 +42,7 @@ extern "C" {
 #define SS_FLAG_GEOM_13 0x200u    /* overlap-save engine: force the software-pipelined B = 4096 geometry (tvfir13.h; default for long filters) */
 #define SS_FLAG_GEOM_ASM 0x400u   /* overlap-save engine: force the hand-scheduled gfx950 assembly kernel (segment / fixed schedules) */
 #define SS_FLAG_LAYOUT_TC 0x100u  /* audio is [T][C] instead of [C][T] (loudness / mix calls) */
+#define SS_FLAG_ASYNC_PLAN 0x800u /* ss_convolve_moving_f32 with device pointers: plan the explicit schedule on the device (no host synchronisation) */
 
 int ss_version(void);
 const char* ss_last_error(void);
@@ -59,6 +60,17 @@ int ss_shutdown(void);
  * gather); w[T] float32.  Replaces oaconvolve (:86) + fancy-index gather (:89-90) + lerp (:94). */
 int ss_convolve_moving_f32(const float* x, int64_t T, const float* rirs, int32_t P, int32_t C, int32_t L,
                            const int64_t* idx, const float* w, float* y, uint32_t flags, void* stream);
+
+/* ---- row V without a host round trip ----------------------------------------------------------
+ * By default ss_convolve_moving_f32 validates 0 <= idx[t] <= P-2 before it returns (the reference's fancy index at
+ * SonicSim_moving.py:89-90 raises IndexError at the call), which costs one device-to-host copy and a stream synchronisation.
+ * With SS_FLAG_DEVICE_PTR | SS_FLAG_ASYNC_PLAN the schedule is planned by a kernel on `stream` and the call only enqueues work:
+ * filter rows that do not exist then contribute nothing (an entry of -1 still takes its end filter, row 0) and the
+ * condition is reported here instead.
+ * ss_async_status synchronises `stream`, returns and clears the latched condition of the current device:
+ * code 0 = none, 1 = interp_index out of range (where = first sample of the offending 1024-sample tile), 2 = schedule too
+ * irregular for the device planner's task buffer (where = row-tasks needed; nothing was rendered: use the default path). */
+int ss_async_status(int32_t* code, int64_t* where, void* stream);
 
 /* ---- rows I+V fused: SonicSim_moving.py:42-45 + :63-96 ---------------------------------------
  * Fast path of interpolate_moving_audio (SonicSim_moving.py:98-125).  The host keeps only the O(P)

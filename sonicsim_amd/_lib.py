@@ -20,6 +20,7 @@ FLAG_GEOM_4096 = 0x80
 FLAG_LAYOUT_TC = 0x100
 FLAG_GEOM_13 = 0x200
 FLAG_GEOM_ASM = 0x400
+FLAG_ASYNC_PLAN = 0x800
 
 SS_EINVAL, SS_EHIP, SS_ENOMEM, SS_ENODEV = -1, -2, -3, -4
 
@@ -44,6 +45,7 @@ _SIGS = {
     "ss_convolve_moving_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32,
                                               ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32,
                                               ctypes.c_void_p]),
+    "ss_async_status": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "ss_convolve_moving_seg_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32,
                                                   ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p]),
     "ss_convolve_fixed_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32,

@@ -123,6 +123,189 @@ __global__ __launch_bounds__(256) void k_idx_minmax(const int64_t* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------
+// Device-side planner of the explicit (idx, w) schedule for the assembly engine (SS_FLAG_ASYNC_PLAN): the task list of plan.h's
+// build_plan + merge_lpt_xcd, produced on the stream from k_idx_minmax's tile bounds -- no copy to the host, no synchronisation.
+// One workgroup of 1024 threads; every stage is a strided loop, so any T / P works (the sort is O(N^2 / 1024): microseconds at
+// BASELINE sizes, milliseconds for hours of audio).  The ORDER of the list only matters for speed (every output sample receives
+// exactly two float atomics, a commutative sum), so the rule is restated in a form that needs no sequential pass:
+//   * row-tasks (row, j0, nj) in time order; cost as in plan.h; `groups` contiguous ranges of equal total cost (one per XCD);
+//   * inside a range by descending cost (ties in time order), channels of a row-task adjacent;
+//   * list position = round-robin over the ranges (element e of range g precedes element e of range g + 1).
+// Out-of-range interp_index values select no filter (the kernel's epilogue compares row - idx with 0 / 1); the first offending
+// tile is latched in status[] for ss_async_status.
+struct PlanDevArgs {
+    const int32_t* bmin;
+    const int32_t* bmax;
+    int64_t nfine;
+    int32_t fine_per_block, nblk, P, C, jmax, NP, groups, cap_rows;
+    int32_t* lo;       // [nblk]
+    int32_t* hi;       // [nblk]
+    int32_t* first;    // [P]
+    int32_t* last;     // [P]
+    int32_t* rcount;   // [P + 1]
+    int32_t* rtask;    // [cap_rows][4]: row, j0, nj, cost
+    unsigned long long* keys;   // [cap_rows]
+    int32_t* out;      // header (16 bytes: ntasks, 0, 0, 0) + Task[cap_rows * C]
+    int32_t* status;   // [0] code (1 = interp_index out of range, 2 = plan capacity exceeded), [1] tile / count, latched
+};
+
+__device__ inline int32_t ld_agent(const int32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__device__ inline int plan_cost(int NP, int j0, int nj) {
+    const int np_eff = NP < j0 + nj ? NP : j0 + nj;
+    const int c = np_eff * (10 + 2 * nj) + 12 * nj;
+    return c < 4096 ? c : 4095;
+}
+
+// exclusive prefix sum of v[0..n) in place (64-bit running total returned to every thread), one workgroup
+template <typename T>
+__device__ inline long long block_exclusive_scan(T* v, int n, long long* sh /*[17]*/) {
+    const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
+    long long carry = 0;
+    for (int base = 0; base < n; base += nt) {
+        const int i = base + tid;
+        const long long x = i < n ? (long long)v[i] : 0;
+        long long incl = x;
+        for (int o = 1; o < 64; o <<= 1) {
+            const long long y = __shfl_up(incl, o);
+            if (lane >= o) incl += y;
+        }
+        if (lane == 63) sh[wave] = incl;
+        __syncthreads();
+        if (tid == 0) {
+            long long run = 0;
+            for (int k = 0; k < nw; ++k) { const long long t = sh[k]; sh[k] = run; run += t; }
+            sh[16] = run;
+        }
+        __syncthreads();
+        if (i < n) v[i] = (T)(carry + sh[wave] + incl - x);
+        carry += sh[16];
+        __syncthreads();
+    }
+    return carry;
+}
+
+__global__ __launch_bounds__(1024) void k_plan_explicit(PlanDevArgs a) {
+    __shared__ long long sh[17];
+    __shared__ unsigned long long tile[1024];
+    __shared__ int gcount[64];
+    const int tid = threadIdx.x, nt = blockDim.x;
+    // ---- 1: per output block min/max of idx, range check, clamp
+    for (int j = tid; j < a.nblk; j += nt) {
+        int lo = INT32_MAX, hi = INT32_MIN;
+        for (int f = 0; f < a.fine_per_block; ++f) {
+            const int64_t fb = (int64_t)j * a.fine_per_block + f;
+            if (fb < a.nfine) {
+                const int l = a.bmin[fb], h = a.bmax[fb];
+                if (l < 0 || h > a.P - 2) {
+                    if (atomicCAS(&a.status[0], 0, 1) == 0) a.status[1] = (int32_t)(fb < INT32_MAX ? fb : INT32_MAX);
+                }
+                lo = l < lo ? l : lo;
+                hi = h > hi ? h : hi;
+            }
+        }
+        if (lo < 0) lo = 0;
+        if (hi > a.P - 2) hi = a.P - 2;
+        if (lo > hi) { lo = 1; hi = -1; }          // nothing valid in this block: the row range lo .. hi + 1 is empty
+        a.lo[j] = lo;
+        a.hi[j] = hi;
+    }
+    for (int r = tid; r < a.P; r += nt) { a.first[r] = INT32_MAX; a.last[r] = -1; }
+    if (tid < 64) gcount[tid] = 0;
+    __syncthreads();
+    // ---- 2: first / last block of every row
+    for (int j = tid; j < a.nblk; j += nt) {
+        const int lo = a.lo[j], hi = a.hi[j];
+        for (int r = lo; r <= hi + 1 && r < a.P; ++r) { atomicMin(&a.first[r], j); atomicMax(&a.last[r], j); }
+    }
+    __syncthreads();
+    // ---- 3: row-tasks per row (runs of consecutive blocks cut into pieces of at most jmax)
+    for (int r = tid; r < a.P; r += nt) {
+        const int f = ld_agent(&a.first[r]), l = ld_agent(&a.last[r]);
+        int cnt = 0, run = 0;
+        for (int j = f; j <= l; ++j) {
+            const bool has = a.lo[j] <= r && r <= a.hi[j] + 1;
+            if (has) { if (run % a.jmax == 0) ++cnt; ++run; } else run = 0;
+        }
+        a.rcount[r] = cnt;
+    }
+    __syncthreads();
+    long long nrow = block_exclusive_scan(a.rcount, a.P, sh);
+    if (nrow > a.cap_rows) {
+        if (tid == 0 && atomicCAS(&a.status[0], 0, 2) == 0) a.status[1] = (int32_t)(nrow < INT32_MAX ? nrow : INT32_MAX);
+        nrow = 0;                                   // render nothing rather than part of the schedule
+    }
+    const int N = (int)nrow;
+    // ---- 4: emit the row-tasks in time order
+    if (N > 0)
+        for (int r = tid; r < a.P; r += nt) {
+            const int f = ld_agent(&a.first[r]), l = ld_agent(&a.last[r]);
+            int k = a.rcount[r] - 1, run = 0, j0 = 0, nj = 0;
+            for (int j = f; j <= l + 1; ++j) {
+                const bool has = j <= l && a.lo[j] <= r && r <= a.hi[j] + 1;
+                if (has && run % a.jmax == 0) {
+                    if (nj) { int32_t* t = a.rtask + 4 * (size_t)k; t[0] = r; t[1] = j0; t[2] = nj; t[3] = plan_cost(a.NP, j0, nj); }
+                    ++k; j0 = j; nj = 0;
+                }
+                if (has) { ++nj; ++run; }
+                else {
+                    if (nj) { int32_t* t = a.rtask + 4 * (size_t)k; t[0] = r; t[1] = j0; t[2] = nj; t[3] = plan_cost(a.NP, j0, nj); nj = 0; }
+                    run = 0;
+                }
+            }
+        }
+    __syncthreads();
+    // ---- 5: ranges of equal total cost, sort keys
+    for (int i = tid; i < N; i += nt) a.keys[i] = (unsigned long long)a.rtask[4 * (size_t)i + 3];
+    __syncthreads();
+    const long long total = block_exclusive_scan(a.keys, N, sh);
+    int groups = a.groups;
+    if (groups > 64) groups = 64;
+    if (groups < 1 || (long long)N * a.C < 2LL * groups) groups = 1;
+    for (int i = tid; i < N; i += nt) {
+        const long long acc = (long long)a.keys[i];
+        const int c = a.rtask[4 * (size_t)i + 3];
+        int g = total > 0 ? (int)((acc + c / 2) * groups / total) : 0;        // total < 2^43: no overflow with groups <= 64
+        if (g >= groups) g = groups - 1;
+        atomicAdd(&gcount[g], 1);
+        a.keys[i] = ((unsigned long long)g << 52) | ((unsigned long long)(4095 - c) << 40) | (unsigned long long)i;
+    }
+    __syncthreads();
+    // ---- 6: rank of every key (keys are unique), then the round-robin position
+    for (int base = 0; base < N; base += nt) {
+        const int i = base + tid;
+        const unsigned long long mine = i < N ? a.keys[i] : 0;
+        int rank = 0;
+        for (int t0 = 0; t0 < N; t0 += 1024) {
+            __syncthreads();
+            if (t0 + tid < N) tile[tid] = a.keys[t0 + tid];
+            __syncthreads();
+            const int m = N - t0 < 1024 ? N - t0 : 1024;
+            for (int k = 0; k < m; ++k) rank += tile[k] < mine ? 1 : 0;
+        }
+        if (i < N) {
+            const int g = (int)(mine >> 52);
+            int gs = 0;
+            for (int q = 0; q < g; ++q) gs += gcount[q];
+            const int32_t* t = a.rtask + 4 * (size_t)i;
+            const long long e0 = (long long)(rank - gs) * a.C;
+            for (int c = 0; c < a.C; ++c) {
+                const long long e = e0 + c;
+                long long pos = 0;
+                for (int q = 0; q < groups; ++q) {
+                    const long long cq = (long long)gcount[q] * a.C;
+                    pos += cq < e ? cq : e;
+                    if (q < g && cq > e) ++pos;
+                }
+                int32_t* o = a.out + 4 + 4 * (size_t)pos;
+                o[0] = t[0]; o[1] = c; o[2] = t[1]; o[3] = t[2];
+            }
+        }
+    }
+    if (tid == 0) { a.out[0] = N * a.C; a.out[1] = 0; a.out[2] = 0; a.out[3] = 0; }
+}
+
+// ---------------------------------------------------------------------------------------------
 // K1: synthetic RIR bank (row R).  Thread per (c,t), sequential AR(1) over positions.
 struct RirDev {
     int32_t P, C, L;
@@ -1085,7 +1268,7 @@ int fail(int code, const char* fmt, ...) {
         if (e_ != hipSuccess) return fail(e_ == hipErrorOutOfMemory ? SS_ENOMEM : SS_EHIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
     } while (0)
 
-enum WsSlot { WS_XS, WS_PLAN, WS_BMIN, WS_BMAX, WS_X, WS_BANK, WS_IDX, WS_W, WS_Y, WS_SCR, WS_SCR2, WS_FILT, WS_META, WS_CNT, WS_LUFS, WS_RES, WS_KWP, WS_KWT, WS_GW, WS_COUNT };
+enum WsSlot { WS_XS, WS_PLAN, WS_BMIN, WS_BMAX, WS_X, WS_BANK, WS_IDX, WS_W, WS_Y, WS_SCR, WS_SCR2, WS_FILT, WS_META, WS_CNT, WS_LUFS, WS_RES, WS_KWP, WS_KWT, WS_GW, WS_DPLAN, WS_DTASKS, WS_COUNT };
 
 struct Pinned {
     void* host = nullptr;
@@ -1139,6 +1322,7 @@ struct Ctx {
     void* gw_cached_dev = nullptr;
     void* kw_cached_dev = nullptr;
     int num_cu = 0;
+    int32_t* async_status = nullptr;      // device: {code, where} latched by k_plan_explicit (SS_FLAG_ASYNC_PLAN), read by ss_async_status
     std::mutex mu;          // one lock per device context: entry points are re-entrant per device (one host thread per GPU works)
 };
 
@@ -1390,6 +1574,38 @@ int render(int mode, const float* x, int64_t T, const float* bank, int32_t P, in
         hipLaunchKernelGGL(k_idx_minmax, dim3((unsigned)nfine), dim3(256), 0, stream, didx, T, (int32_t*)c->ws[WS_BMIN],
                            (int32_t*)c->ws[WS_BMAX]);
         HIPCHK(hipGetLastError());
+    }
+    // explicit schedule planned on the device (assembly engine, device pointers): nothing comes back to the host
+    const bool dev_plan = mode == COEF_EXPLICIT && g14 && dev && (flags & SS_FLAG_ASYNC_PLAN);
+    int32_t* dplan_out = nullptr;
+    if (dev_plan) {
+        const int nblk = M;
+        const int64_t cap64 = 4 * ((int64_t)P + 2 * (int64_t)nblk) + 64;
+        if (cap64 * C > ((int64_t)1 << 27)) return fail(SS_EINVAL, "schedule too large for the device planner (use the synchronous explicit path)");
+        const int32_t cap_rows = (int32_t)cap64;
+        auto al = [](size_t n) { return (n + 255) & ~(size_t)255; };
+        const size_t o_lo = 0, o_hi = o_lo + al(4 * (size_t)nblk), o_first = o_hi + al(4 * (size_t)nblk), o_last = o_first + al(4 * (size_t)P),
+                     o_rc = o_last + al(4 * (size_t)P), o_rt = o_rc + al(4 * ((size_t)P + 1)), o_keys = o_rt + al(16 * (size_t)cap_rows),
+                     o_end = o_keys + al(8 * (size_t)cap_rows);
+        if ((rc = ws_ensure(c, WS_DPLAN, o_end))) return rc;
+        if ((rc = ws_ensure(c, WS_DTASKS, 16 + sizeof(Task) * (size_t)cap_rows * C))) return rc;
+        if (!c->async_status) {
+            HIPCHK(hipMalloc((void**)&c->async_status, 16));
+            HIPCHK(hipMemsetAsync(c->async_status, 0, 16, stream));
+        }
+        char* base = (char*)c->ws[WS_DPLAN];
+        PlanDevArgs pa;
+        pa.bmin = (const int32_t*)c->ws[WS_BMIN]; pa.bmax = (const int32_t*)c->ws[WS_BMAX]; pa.nfine = nfine;
+        pa.fine_per_block = BB / DTILE; pa.nblk = nblk; pa.P = P; pa.C = C; pa.jmax = JM; pa.NP = NPart; pa.groups = 8; pa.cap_rows = cap_rows;
+        pa.lo = (int32_t*)(base + o_lo); pa.hi = (int32_t*)(base + o_hi); pa.first = (int32_t*)(base + o_first); pa.last = (int32_t*)(base + o_last);
+        pa.rcount = (int32_t*)(base + o_rc); pa.rtask = (int32_t*)(base + o_rt); pa.keys = (unsigned long long*)(base + o_keys);
+        pa.out = dplan_out = (int32_t*)c->ws[WS_DTASKS];
+        pa.status = c->async_status;
+        hipLaunchKernelGGL(k_plan_explicit, dim3(1), dim3(1024), 0, stream, pa);
+        HIPCHK(hipGetLastError());
+        c->plan.tasks[0].clear();
+        c->plan.tasks[1].clear();
+    } else if (mode == COEF_EXPLICIT) {
         c->bmin.resize(nfine);
         c->bmax.resize(nfine);
         HIPCHK(hipMemcpyAsync(c->bmin.data(), c->ws[WS_BMIN], sizeof(int32_t) * nfine, hipMemcpyDeviceToHost, stream));
@@ -1401,7 +1617,8 @@ int render(int mode, const float* x, int64_t T, const float* bank, int32_t P, in
                             (long long)(b * DTILE), c->bmin[b], c->bmax[b]);
     }
     const bool fast_plan = g12 && mode == COEF_SEG;        // single-launch geometries, implicit schedule: O(P*C) direct planner
-    if (fast_plan) {
+    if (dev_plan) {
+    } else if (fast_plan) {
         // XCD-aware task order for the persistent assembly kernel (workgroup b -> XCD b % 8 takes tasks b, b + nwg, ...)
         static const int plan_groups = getenv("SS_PLAN_GROUPS") ? atoi(getenv("SS_PLAN_GROUPS")) : 8;
         static const int plan_snake = getenv("SS_PLAN_SNAKE") ? atoi(getenv("SS_PLAN_SNAKE")) : 1;
@@ -1417,7 +1634,7 @@ int render(int mode, const float* x, int64_t T, const float* bank, int32_t P, in
 
     // ---- upload plan blob: [seg_start (P int64)][tasks parity 0][tasks parity 1]
     //      geometry 12: ONE list in LPT order (atomic accumulation, persistent workgroups)
-    if (g12 && !fast_plan) {
+    if (g12 && !fast_plan && !dev_plan) {
         if (g14) merge_lpt_xcd(c->plan, NPart, 8, c->merged, c->plan_scratch);     // same XCD-aware order as the implicit schedule's planner
         else merge_lpt(c->plan, NPart, c->merged);
         c->plan.tasks[0].swap(c->merged);
@@ -1488,9 +1705,10 @@ int render(int mode, const float* x, int64_t T, const float* bank, int32_t P, in
     const Task* dtasks = (const Task*)(plan_base + seg_bytes);
     for (int parity = 0; parity < 2; ++parity) {
         size_t nt = parity ? n1 : n0;
+        if (dev_plan) nt = parity ? 0 : (size_t)c->num_cu;      // the count lives in the list's header: every CU gets a workgroup
         if (!nt) continue;
-        prm.tasks = dtasks + (parity ? n0 : 0);
-        prm.ntasks = (int32_t)nt;
+        prm.tasks = dev_plan ? (const Task*)dplan_out : dtasks + (parity ? n0 : 0);
+        prm.ntasks = dev_plan ? -1 : (int32_t)nt;
         prm.accumulate = g12 ? 2 : parity;
         if (g12 && nt > (size_t)c->num_cu) nt = (size_t)c->num_cu;     // persistent: one workgroup per CU
         ProfScope ps(c, stream, use_os ? 0 : 2);
@@ -1619,6 +1837,24 @@ int ss_shutdown(void) {
 int ss_convolve_moving_f32(const float* x, int64_t T, const float* rirs, int32_t P, int32_t C, int32_t L, const int64_t* idx,
                            const float* w, float* y, uint32_t flags, void* stream) {
     return render(COEF_EXPLICIT, x, T, rirs, P, C, L, nullptr, idx, w, y, flags, stream);
+}
+
+int ss_async_status(int32_t* code, int64_t* where, void* stream_) {
+    Ctx* c;
+    int rc = get_ctx(&c);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lock(c->mu);
+    if (code) *code = 0;
+    if (where) *where = 0;
+    if (!c->async_status) return SS_OK;
+    hipStream_t stream = (hipStream_t)stream_;
+    int32_t h[4] = {0, 0, 0, 0};
+    HIPCHK(hipMemcpyAsync(h, c->async_status, 16, hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    if (h[0]) HIPCHK(hipMemsetAsync(c->async_status, 0, 16, stream));
+    if (code) *code = h[0];
+    if (where) *where = h[0] == 1 ? (int64_t)h[1] * DTILE : (int64_t)h[1];
+    return SS_OK;
 }
 
 int ss_convolve_moving_seg_f32(const float* x, int64_t T, const float* rirs, int32_t P, int32_t C, int32_t L,

@@ -76,8 +76,10 @@ def _out_ct(out, C, T, dev):
     return out
 
 
-def convolve_moving(x, rirs, idx, w, path=None):
-    """Row V (SonicSim_moving.py:63-96).  x (T,), rirs (P,C,L), idx (T,) int, w (T,) -> (C,T)."""
+def convolve_moving(x, rirs, idx, w, path=None, out=None, validate=True):
+    """Row V (SonicSim_moving.py:63-96).  x (T,), rirs (P,C,L), idx (T,) int, w (T,) -> (C,T).
+    validate=False (device tensors, assembly engine): the schedule is planned on the device and the call only enqueues work --
+    no host synchronisation; an out-of-range interp_index is then reported by ``async_status()`` instead of a ValueError here."""
     lib = _lib.load()
     flags = PATHS[path]
     if _is_dev(x) or _is_dev(rirs):
@@ -91,9 +93,9 @@ def convolve_moving(x, rirs, idx, w, path=None):
         P, C, L = rirs.shape
         T = x.shape[0]
         _set_device(x)
-        y = torch.empty((C, T), dtype=torch.float32, device=dev)
+        y = _out_ct(out, C, T, dev)
         _lib.check(lib.ss_convolve_moving_f32(_ptr(x), T, _ptr(rirs), P, C, L, _ptr(idx), _ptr(w), _ptr(y),
-                                              flags | _lib.FLAG_DEVICE_PTR, _stream_ptr(x)))
+                                              flags | _lib.FLAG_DEVICE_PTR | (0 if validate else _lib.FLAG_ASYNC_PLAN), _stream_ptr(x)))
         return y
     x = _np32(x, "x")
     rirs = _np32(rirs, "rirs")
@@ -107,6 +109,22 @@ def convolve_moving(x, rirs, idx, w, path=None):
     y = np.empty((C, T), dtype=np.float32)
     _lib.check(lib.ss_convolve_moving_f32(_ptr(x), T, _ptr(rirs), P, C, L, _ptr(idx), _ptr(w), _ptr(y), flags, None))
     return y
+
+
+def async_status(stream_of=None):
+    """stream_of: a device tensor whose device's current stream is synchronised (default: the current device's current stream).
+    (code, where) latched by renders issued with validate=False on the current device, then cleared: 0 = none,
+    1 = interp_index out of range near sample `where`, 2 = schedule too irregular for the device planner.  Synchronises the stream."""
+    lib = _lib.load()
+    code = ctypes.c_int32(0)
+    where = ctypes.c_int64(0)
+    if stream_of is not None:
+        stream = _stream_ptr(stream_of)
+    else:
+        import torch
+        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _lib.check(lib.ss_async_status(ctypes.byref(code), ctypes.byref(where), stream))
+    return int(code.value), int(where.value)
 
 
 def _check_moving_shapes(x, rirs, idx, w):

@@ -1,0 +1,111 @@
+"""Row V without a host round trip (SS_FLAG_ASYNC_PLAN): the explicit (idx, w) schedule of SonicSim_moving.py:63-96 planned by
+k_plan_explicit on the device must produce the SAME BITS as the host-planned path (every output sample is the commutative sum of two
+float atomics, so the task order cannot change a result -- a missing or duplicated task would)."""
+import numpy as np
+import pytest
+
+from tests import util
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def _setup(T, P, C, L, seed):
+    from sonicsim_amd import ops
+    rng = np.random.default_rng(seed)
+    dev = torch.device("cuda:0")
+    x = torch.from_numpy(rng.standard_normal(T).astype(np.float32)).to(dev)
+    bank = torch.from_numpy((rng.standard_normal((P, C, L)) * np.exp(-np.arange(L) / (L / 6.0))).astype(np.float32)).to(dev)
+    return ops, rng, dev, x, bank
+
+
+def _both(ops, x, bank, idx, w):
+    dev = x.device
+    di, dw = torch.from_numpy(idx).to(dev), torch.from_numpy(w).to(dev)
+    y_sync = ops.convolve_moving(x, bank, di, dw, path="asm")
+    y_async = ops.convolve_moving(x, bank, di, dw, path="asm", validate=False)
+    return y_sync, y_async
+
+
+@pytest.mark.parametrize("T,P,C,L", [(70001, 12, 2, 20000), (200000, 30, 2, 48000), (150000, 4, 1, 30000), (40000, 2, 3, 9000), (5000, 7, 1, 4097)])
+def test_monotone_schedules_bitwise(T, P, C, L):
+    from oracle import moving as O
+    ops, rng, dev, x, bank = _setup(T, P, C, L, 11)
+    cuts = np.sort(rng.integers(0, T + 1, P - 2))
+    seg = np.diff(np.concatenate([[0], cuts, [T]])).astype(np.int64)
+    if P > 3:
+        seg[1] += seg[2]
+        seg[2] = 0                                   # a zero-length segment
+    idx, w = O.expand_segments(seg)
+    y_sync, y_async = _both(ops, x, bank, idx, w)
+    assert torch.equal(y_sync, y_async)
+    assert ops.async_status() == (0, 0)
+    y_seg = ops.convolve_moving_seg(x, bank, seg, path="asm")
+    assert torch.equal(y_seg, y_async)
+    ref = O.convolve_moving_receiver(x.cpu().numpy(), bank.cpu().numpy(), idx, w)
+    assert O.rel_rms(y_async.cpu().numpy(), ref) <= 1e-4
+
+
+def test_non_monotone_schedules_bitwise():
+    """SonicSim_moving.py:89-94 is a pure gather: any idx in [0, P-2] is legal (back and forth, jumps, constant)."""
+    from oracle import moving as O
+    T, P, C, L = 120000, 16, 2, 12000
+    ops, rng, dev, x, bank = _setup(T, P, C, L, 5)
+    t = np.arange(T)
+    schedules = {
+        "back and forth": np.abs(((t // 3000) % (2 * (P - 2))) - (P - 2)),
+        "jumps": rng.integers(0, P - 1, T // 5000 + 1)[t // 5000],
+        "constant": np.full(T, 3),
+        "two far rows alternating every 700 samples": np.where((t // 700) % 2 == 0, 1, P - 2),
+        "used only in the middle": np.where((t > 30000) & (t < 50000), 9, 2),
+    }
+    for name, idx in schedules.items():
+        idx = idx.astype(np.int64)
+        w = rng.random(T).astype(np.float32)
+        y_sync, y_async = _both(ops, x, bank, idx, w)
+        assert torch.equal(y_sync, y_async), name
+        assert ops.async_status() == (0, 0), name
+    ref = O.convolve_moving_receiver(x.cpu().numpy(), bank.cpu().numpy(), idx, w)
+    assert O.rel_rms(y_async.cpu().numpy(), ref) <= 1e-4
+
+
+def test_out_of_range_is_latched_not_raised():
+    T, P, C, L = 60000, 6, 1, 9000
+    ops, rng, dev, x, bank = _setup(T, P, C, L, 3)
+    idx = np.minimum(np.arange(T) // 12000, P - 2).astype(np.int64)
+    w = rng.random(T).astype(np.float32)
+    bad = idx.copy()
+    bad[33000:33010] = P - 1                          # one past the last legal start filter
+    di, dw = torch.from_numpy(bad).to(dev), torch.from_numpy(w).to(dev)
+    with pytest.raises(ValueError):
+        ops.convolve_moving(x, bank, di, dw, path="asm")
+    y = ops.convolve_moving(x, bank, di, dw, path="asm", validate=False)
+    code, where = ops.async_status()
+    assert code == 1 and where == (33000 // 1024) * 1024
+    assert ops.async_status() == (0, 0)               # cleared by the read
+    good = ops.convolve_moving(x, bank, torch.from_numpy(idx).to(dev), dw, path="asm", validate=False)
+    assert ops.async_status() == (0, 0)
+    keep = np.ones(T, bool)
+    keep[33000:33010] = False
+    assert torch.equal(y[:, torch.from_numpy(keep).to(dev)], good[:, torch.from_numpy(keep).to(dev)])
+    assert torch.isfinite(y).all()
+
+
+def test_planner_capacity_is_reported():
+    """A schedule that touches every row in every block needs more row-tasks than the device planner's buffer holds: nothing is
+    rendered and the condition is latched; the default (host-planned) path still renders it."""
+    from oracle import moving as O
+    T, P, C, L = 204800, 200, 1, 5000
+    ops, rng, dev, x, bank = _setup(T, P, C, L, 9)
+    t = np.arange(T)
+    idx = np.where((t // 64) % 2 == 0, (t // 128) % (P - 1), P - 2 - (t // 128) % (P - 1)).astype(np.int64)
+    w = rng.random(T).astype(np.float32)
+    di, dw = torch.from_numpy(idx).to(dev), torch.from_numpy(w).to(dev)
+    y = ops.convolve_moving(x, bank, di, dw, path="asm", validate=False)
+    code, where = ops.async_status()
+    assert code == 2 and where > 4 * (P + 2 * 50) + 64
+    assert not y.any()
+    y_sync = ops.convolve_moving(x, bank, di, dw, path="asm")
+    sel = slice(100000, 101000)
+    ref = O.convolve_moving_receiver(x.cpu().numpy(), bank.cpu().numpy(), idx, w)
+    assert O.rel_rms(y_sync.cpu().numpy()[:, sel], ref[:, sel]) <= 1e-4

@@ -64,6 +64,8 @@ from oracle import moving as O  # noqa: E402  (only to expand the schedule)
 idx, w = O.expand_segments(s0)
 di, dw = torch.from_numpy(idx).to(dev), torch.from_numpy(w).to(dev)
 out["cfg2_moving_explicit_ms"] = timeit(lambda: ops.convolve_moving(x0, b0, di, dw)) * 1e3
+out["cfg2_moving_explicit_async_plan_ms"] = timeit(lambda: ops.convolve_moving(x0, b0, di, dw, validate=False)) * 1e3     # planned on the device
+out["async_status"] = list(ops.async_status())
 # bank chain (rows R + G): generator with tracked peak, one-pass materialisation, stand-alone abs().max() + divide
 sc2 = synth.make_scene("cfg2", scene=0)
 out["bank_synth_peak_ms"] = timeit(lambda: ops.rir_bank_synth(sc2.delay, sc2.dgain, sc2.L, sc2.fs, sc2.rt60, sc2.bank_seed, device=dev, return_peak=True), n=10) * 1e3
