@@ -176,12 +176,28 @@ inline void merge_lpt_xcd(Plan& plan, int NP, int groups, std::vector<Task>& out
 // own, and the ranges are interleaved task by task, so that position i of the list belongs to range i % groups.  Each XCD then
 // works on one stretch of the trajectory and its L2 only has to hold that stretch's input spectra (1/groups of the set).
 // nwg = number of persistent workgroups (0 = unknown: plain round-robin dealing).
+// rs > 0 (assembly engine): the input spectra exist on a grid of block >> rs samples, so a row's first block may start at any
+// multiple of that hop instead of a multiple of `block` -- a row of 2.3 blocks then never spills into a fourth block and fewer
+// rows need a second task.  Task::j0 is in HOP units (first sample = j0 * (block >> rs)); blocks of a task stay `block` apart.
+template <class F> inline void row_tasks(int64_t a0, int64_t a2, int block, int jmax, int rs, F f) {
+    if (a2 <= a0) return;
+    const int64_t hop = block >> rs;
+    int64_t jh = a0 / hop;
+    int64_t nb = (a2 - jh * hop + block - 1) / block;
+    while (nb > 0) {
+        const int nj = (int)std::min<int64_t>(jmax, nb);
+        f((int)jh, nj);
+        jh += (int64_t)nj << rs;
+        nb -= nj;
+    }
+}
+
 inline void plan_seg_lpt(const std::vector<int64_t>& seg_start /*[P], last == T*/, int P, int C, int block, int jmax, int NP,
-                         std::vector<Task>& out, std::vector<int32_t>& scratch, int groups = 1, int nwg = 0) {
+                         std::vector<Task>& out, std::vector<int32_t>& scratch, int groups = 1, int nwg = 0, int rs = 0) {
     out.clear();
     constexpr int MAXCOST = 4096;
-    auto cost = [NP](int j0, int nj) {
-        const int np_eff = std::min(NP, j0 + nj);
+    auto cost = [NP, rs](int j0, int nj) {
+        const int np_eff = std::min(NP, ((j0 + (1 << rs) - 1) >> rs) + nj);
         const int c = np_eff * (10 + 2 * nj) + 12 * nj;
         return c < MAXCOST ? c : MAXCOST - 1;
     };
@@ -193,15 +209,7 @@ inline void plan_seg_lpt(const std::vector<int64_t>& seg_start /*[P], last == T*
         for (int r = 0; r < P; ++r) {
             const int64_t a0 = seg_start[r > 0 ? r - 1 : r], a2 = seg_start[r < P - 1 ? r + 1 : r];
             int64_t rc = 0;
-            if (a2 > a0) {
-                int64_t j = a0 / block;
-                const int64_t jhi = (a2 - 1) / block;
-                while (j <= jhi) {
-                    const int nj = (int)std::min<int64_t>(jmax, jhi - j + 1);
-                    rc += cost((int)j, nj);
-                    j += nj;
-                }
-            }
+            row_tasks(a0, a2, block, jmax, rs, [&](int j, int nj) { rc += cost(j, nj); });
             rowcost[(size_t)r + 1] = rowcost[(size_t)r] + rc;
         }
         const int64_t total_cost = rowcost[(size_t)P];
@@ -218,14 +226,10 @@ inline void plan_seg_lpt(const std::vector<int64_t>& seg_start /*[P], last == T*
             const int64_t a0 = seg_start[r > 0 ? r - 1 : r], a2 = seg_start[r < P - 1 ? r + 1 : r];
             if (a2 <= a0) continue;
             const int g = group_of(r);
-            int64_t j = a0 / block;
-            const int64_t jhi = (a2 - 1) / block;
-            while (j <= jhi) {
-                const int nj = (int)std::min<int64_t>(jmax, jhi - j + 1);
-                hist[(size_t)g * MAXCOST + cost((int)j, nj)] += C;
+            row_tasks(a0, a2, block, jmax, rs, [&](int j, int nj) {
+                hist[(size_t)g * MAXCOST + cost(j, nj)] += C;
                 gcount[g] += C;
-                j += nj;
-            }
+            });
         }
         int32_t total = 0;
         for (int g = 0; g < groups; ++g)
@@ -235,18 +239,14 @@ inline void plan_seg_lpt(const std::vector<int64_t>& seg_start /*[P], last == T*
             const int64_t a0 = seg_start[r > 0 ? r - 1 : r], a2 = seg_start[r < P - 1 ? r + 1 : r];
             if (a2 <= a0) continue;
             const int g = group_of(r);
-            int64_t j = a0 / block;
-            const int64_t jhi = (a2 - 1) / block;
-            while (j <= jhi) {
-                const int nj = (int)std::min<int64_t>(jmax, jhi - j + 1);
-                int32_t& at = hist[(size_t)g * MAXCOST + cost((int)j, nj)];
+            row_tasks(a0, a2, block, jmax, rs, [&](int j, int nj) {
+                int32_t& at = hist[(size_t)g * MAXCOST + cost(j, nj)];
                 for (int c = 0; c < C; ++c) {
                     Task t;
                     t.row = r; t.chan = c; t.j0 = (int32_t)j; t.nj = nj;
                     tmp[(size_t)at++] = t;
                 }
-                j += nj;
-            }
+            });
         }
         // interleave: position i takes the next task of range i % groups (or of the next range that still has one)
         out.resize((size_t)total);
@@ -270,14 +270,7 @@ inline void plan_seg_lpt(const std::vector<int64_t>& seg_start /*[P], last == T*
     // pass 1: histogram of costs
     for (int r = 0; r < P; ++r) {
         const int64_t a0 = seg_start[r > 0 ? r - 1 : r], a2 = seg_start[r < P - 1 ? r + 1 : r];
-        if (a2 <= a0) continue;
-        int64_t j = a0 / block;
-        const int64_t jhi = (a2 - 1) / block;
-        while (j <= jhi) {
-            const int nj = (int)std::min<int64_t>(jmax, jhi - j + 1);
-            scratch[cost((int)j, nj)] += C;
-            j += nj;
-        }
+        row_tasks(a0, a2, block, jmax, rs, [&](int j, int nj) { scratch[cost(j, nj)] += C; });
     }
     // descending-cost start offsets
     int32_t total = 0;
@@ -286,19 +279,14 @@ inline void plan_seg_lpt(const std::vector<int64_t>& seg_start /*[P], last == T*
     // pass 2: scatter
     for (int r = 0; r < P; ++r) {
         const int64_t a0 = seg_start[r > 0 ? r - 1 : r], a2 = seg_start[r < P - 1 ? r + 1 : r];
-        if (a2 <= a0) continue;
-        int64_t j = a0 / block;
-        const int64_t jhi = (a2 - 1) / block;
-        while (j <= jhi) {
-            const int nj = (int)std::min<int64_t>(jmax, jhi - j + 1);
-            int32_t& at = scratch[cost((int)j, nj)];
+        row_tasks(a0, a2, block, jmax, rs, [&](int j, int nj) {
+            int32_t& at = scratch[cost(j, nj)];
             for (int c = 0; c < C; ++c) {
                 Task t;
                 t.row = r; t.chan = c; t.j0 = (int32_t)j; t.nj = nj;
                 out[(size_t)at++] = t;
             }
-            j += nj;
-        }
+        });
     }
 }
 

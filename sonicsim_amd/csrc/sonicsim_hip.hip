@@ -71,11 +71,11 @@ template <int ABL = 0> __global__ __launch_bounds__(512, 2) void k_os12(RenderPa
 // counter: task-queue heads of the render kernel that follows -- ncnt words, 64 bytes apart, each set to cnt_init
 __global__ __launch_bounds__(512, 2) void k_xspec13(const float* __restrict__ x, int64_t T, const c32* __restrict__ consts,
                                                     c32* __restrict__ Xs, int M, float* __restrict__ yzero, int64_t nzero,
-                                                    int* __restrict__ counter, int ncnt, int cnt_init, const float* __restrict__ xdiv) {
+                                                    int* __restrict__ counter, int ncnt, int cnt_init, const float* __restrict__ xdiv, int rs) {
     __shared__ __attribute__((aligned(16))) c32 smem[LDS13_C32];
     DevEnv env{smem};
     if (counter && blockIdx.x == 0 && (int)threadIdx.x < ncnt) counter[16 * threadIdx.x] = cnt_init;
-    xspec13_body(env, x, T, consts, Xs, (int)blockIdx.x, M, yzero, nzero, xdiv);
+    xspec13_body(env, x, T, consts, Xs, (int)blockIdx.x, M, yzero, nzero, xdiv, rs);
 }
 
 // geometry 13 (tvfir13.h): software-pipelined FFT/MAC, one barrier per transform, buffer addressing, dynamic task queue
@@ -137,7 +137,7 @@ struct PlanDevArgs {
     const int32_t* bmin;
     const int32_t* bmax;
     int64_t nfine;
-    int32_t fine_per_block, nblk, P, C, jmax, NP, groups, cap_rows;
+    int32_t fine_per_block, nblk, P, C, jmax, NP, groups, cap_rows, rs;      // rs: Task::j0 is emitted in hop units (j0 << rs)
     int32_t* lo;       // [nblk]
     int32_t* hi;       // [nblk]
     int32_t* first;    // [P]
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(1024) void k_plan_explicit(PlanDevArgs a) {
                     if (q < g && cq > e) ++pos;
                 }
                 int32_t* o = a.out + 4 + 4 * (size_t)pos;
-                o[0] = t[0]; o[1] = c; o[2] = t[1]; o[3] = t[2];
+                o[0] = t[0]; o[1] = c; o[2] = t[1] << a.rs; o[3] = t[2];
             }
         }
     }
@@ -1461,7 +1461,7 @@ struct Os13AsmArgs {
     const void* idx;       // explicit schedule (mode 2): interp_index int64[T], interp_weight float[T]
     const void* w;
     int32_t qgroups;       // dynamic task queues: 0 = static stride-nwg assignment, G = workgroup b pulls from queue b % G (counter[16 * g])
-    int32_t pad_;
+    int32_t rs;            // input spectra every 4096 >> rs samples; Task::j0 in those hop units (plan.h row_tasks)
 };
 static_assert(sizeof(Os13AsmArgs) == 128, "Os13AsmArgs layout");
 
@@ -1553,7 +1553,13 @@ int render(int mode, const float* x, int64_t T, const float* bank, int32_t P, in
     }
     const int BB = g12 ? B12 : B;
     const int JM = g12 ? JMAX12 : JMAX;
-    const int M = (int)((T + BB - 1) / BB);
+    // assembly engine, EXPERIMENT (SS_HOP_RS = 1 / 2; default 0 = the block grid): input spectra on a grid of B >> rs samples so that a
+    // row's first block starts within one hop of its first sample (plan.h row_tasks) -- 8 % fewer blocks and 6 % fewer tasks at config 2,
+    // but the kernel gains only 1.5 % (twice the spectra in L2), the spectra kernel loses as much, and the implicit schedule is no longer
+    // bit-identical to the explicit one (different block decomposition): profiles/r02r.
+    static const int hop_rs_env = getenv("SS_HOP_RS") ? atoi(getenv("SS_HOP_RS")) : 0;
+    const int rs = g14 ? (hop_rs_env < 0 ? 0 : (hop_rs_env > 2 ? 2 : hop_rs_env)) : 0;
+    const int M = g14 ? (int)((T + (BB >> rs) - 1) / (BB >> rs)) + (1 << rs) - 1 : (int)((T + BB - 1) / BB);   // number of input spectra
     const int NPart = (L + BB - 1) / BB;
 
     // ---- schedule -> per-tile min/max of idx
@@ -1579,7 +1585,7 @@ int render(int mode, const float* x, int64_t T, const float* bank, int32_t P, in
     const bool dev_plan = mode == COEF_EXPLICIT && g14 && dev && (flags & SS_FLAG_ASYNC_PLAN);
     int32_t* dplan_out = nullptr;
     if (dev_plan) {
-        const int nblk = M;
+        const int nblk = (int)((T + BB - 1) / BB);
         const int64_t cap64 = 4 * ((int64_t)P + 2 * (int64_t)nblk) + 64;
         if (cap64 * C > ((int64_t)1 << 27)) return fail(SS_EINVAL, "schedule too large for the device planner (use the synchronous explicit path)");
         const int32_t cap_rows = (int32_t)cap64;
@@ -1596,7 +1602,7 @@ int render(int mode, const float* x, int64_t T, const float* bank, int32_t P, in
         char* base = (char*)c->ws[WS_DPLAN];
         PlanDevArgs pa;
         pa.bmin = (const int32_t*)c->ws[WS_BMIN]; pa.bmax = (const int32_t*)c->ws[WS_BMAX]; pa.nfine = nfine;
-        pa.fine_per_block = BB / DTILE; pa.nblk = nblk; pa.P = P; pa.C = C; pa.jmax = JM; pa.NP = NPart; pa.groups = 8; pa.cap_rows = cap_rows;
+        pa.fine_per_block = BB / DTILE; pa.nblk = nblk; pa.P = P; pa.C = C; pa.jmax = JM; pa.NP = NPart; pa.groups = 8; pa.cap_rows = cap_rows; pa.rs = rs;
         pa.lo = (int32_t*)(base + o_lo); pa.hi = (int32_t*)(base + o_hi); pa.first = (int32_t*)(base + o_first); pa.last = (int32_t*)(base + o_last);
         pa.rcount = (int32_t*)(base + o_rc); pa.rtask = (int32_t*)(base + o_rt); pa.keys = (unsigned long long*)(base + o_keys);
         pa.out = dplan_out = (int32_t*)c->ws[WS_DTASKS];
@@ -1623,7 +1629,7 @@ int render(int mode, const float* x, int64_t T, const float* bank, int32_t P, in
         static const int plan_groups = getenv("SS_PLAN_GROUPS") ? atoi(getenv("SS_PLAN_GROUPS")) : 8;
         static const int plan_snake = getenv("SS_PLAN_SNAKE") ? atoi(getenv("SS_PLAN_SNAKE")) : 1;
         plan_seg_lpt(c->seg_start, P, C, BB, JM, NPart, c->plan.tasks[0], c->plan_scratch, (g14 && plan_groups > 1 && plan_groups <= 64) ? plan_groups : 1,
-                     plan_snake ? c->num_cu : 0);
+                     plan_snake ? c->num_cu : 0, rs);
         c->plan.tasks[1].clear();
     } else {
         if (mode == COEF_SEG) seg_minmax(c->seg_start, T, c->bmin, c->bmax);
@@ -1639,6 +1645,8 @@ int render(int mode, const float* x, int64_t T, const float* bank, int32_t P, in
         else merge_lpt(c->plan, NPart, c->merged);
         c->plan.tasks[0].swap(c->merged);
         c->plan.tasks[1].clear();
+        if (rs)                                     // these planners work on the block grid: the same tasks in hop units
+            for (Task& t : c->plan.tasks[0]) t.j0 <<= rs;
     }
     const size_t n0 = c->plan.tasks[0].size(), n1 = c->plan.tasks[1].size();
     const size_t seg_bytes = 2 * sizeof(int64_t) * (size_t)P;      // [seg_start P x i64][inv_seg P x f64: 1/len(segment k), IEEE double division]
@@ -1695,7 +1703,7 @@ int render(int mode, const float* x, int64_t T, const float* bank, int32_t P, in
             }
             if (g13 || g14) hipLaunchKernelGGL(k_xspec13, dim3(M + 1), dim3(NT13), 0, stream, dx, T, (const c32*)c->consts13, (c32*)c->ws[WS_XS], M,
                                                dy, (int64_t)C * T, (g13 || qgroups) ? (int*)c->ws[WS_CNT] : (int*)nullptr, g13 ? 1 : qgroups,
-                                               g13 ? 0 : qinit, xdiv);
+                                               g13 ? 0 : qinit, xdiv, rs);
             else if (g12) hipLaunchKernelGGL(k_xspec12, dim3(M + 1), dim3(NT12), 0, stream, dx, T, (const c32*)c->consts12, (c32*)c->ws[WS_XS], M,
                                         dy, (int64_t)C * T, (int*)nullptr);
             else hipLaunchKernelGGL(k_xspec, dim3(M + 1), dim3(NT), 0, stream, dx, T, (const c32*)c->consts, (c32*)c->ws[WS_XS], M);
@@ -1721,7 +1729,7 @@ int render(int mode, const float* x, int64_t T, const float* bank, int32_t P, in
             a.ntasks = prm.ntasks; a.mode = mode; a.nwg = (int32_t)nt;
             a.consts = c->consts14; a.counter = qgroups ? c->ws[WS_CNT] : nullptr;
             a.idx = didx; a.w = dw;
-            a.qgroups = qgroups; a.pad_ = 0;
+            a.qgroups = qgroups; a.rs = rs;
             const char* trace_file = trace_env;
             if (trace_file) a.counter = c->ws[WS_CNT];     // (zeroed ahead of the spectra kernel, which then sets the queue heads)
             size_t asz = sizeof(a);

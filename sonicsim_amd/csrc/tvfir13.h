@@ -337,8 +337,11 @@ SS_HD void g13_step(Env& env, const Lds13& l, const P& prm, const Task13& tk, St
 // spectrum in the slot layout the render kernels read (c32 index ((r>>1)*512 + tid)*2 + (r&1)).
 // xdiv != nullptr: the spectra are those of x / *xdiv -- the render is linear in x, so this is how a bank's deferred global
 // peak normalisation (SonicSim_audio.py:398, ir_output /= ir_output.abs().max()) reaches the output without a pass over the bank
+// rs > 0: spectra on a grid of B13 >> rs samples for the assembly engine's hop-aligned tasks (plan.h row_tasks): entry m is the
+// window that starts at (m - (2^rs - 1)) * (B13 >> rs) - B13, i.e. the 2^rs - 1 windows that begin before -B13 + hop .. are kept too
+// (they still cover samples of x); rs = 0 is the block grid the other engines use.
 template <class Env> SS_HD void xspec13_body(Env& env, const float* x, int64_t T, const c32* consts, c32* Xs, int m, int M,
-                                             float* yzero, int64_t nzero, const float* xdiv = nullptr) {
+                                             float* yzero, int64_t nzero, const float* xdiv = nullptr, int rs = 0) {
     const int tid = env.tid();
     float lo[8], hi[8];
     if (m < M) {
@@ -346,9 +349,9 @@ template <class Env> SS_HD void xspec13_body(Env& env, const float* x, int64_t T
 #pragma unroll
         for (int n1 = 0; n1 < 8; ++n1) {
             const int n = n1 * 512 + tid;
-            const int64_t tlo = (int64_t)(m - 1) * B13 + n, thi = (int64_t)m * B13 + n;
+            const int64_t thi = ((int64_t)m - ((1 << rs) - 1)) * (B13 >> rs) + n, tlo = thi - B13;
             lo[n1] = (tlo >= 0 && tlo < T) ? x[tlo] : 0.0f;
-            hi[n1] = (thi < T) ? x[thi] : 0.0f;
+            hi[n1] = (thi >= 0 && thi < T) ? x[thi] : 0.0f;
             if (xdiv) { lo[n1] *= xs; hi[n1] *= xs; }
         }
     }
