@@ -384,6 +384,7 @@ __global__ __launch_bounds__(256) void k_rir_synth(RirDev p, float* __restrict__
         }
         if (live) {
             if (V == 4) *reinterpret_cast<float4*>(out) = make_float4(val[0], val[1], val[2], val[3]);
+            else if (V == 2) *reinterpret_cast<float2*>(out) = make_float2(val[0], val[V - 1]);
             else
 #pragma unroll
                 for (int v = 0; v < V; ++v) out[v] = val[v];
@@ -1929,9 +1930,16 @@ static int rir_synth(const SsRirParams* p, float* bank, float* peak, uint32_t fl
     d.dgain = (const float*)((const char*)c->ws[WS_META] + pc * sizeof(int32_t));
     const int64_t CL = (int64_t)p->C * p->L;
     const bool fast32 = (uint64_t)pc * (uint64_t)p->L < ((uint64_t)1 << 32);
-    const bool vec4 = p->L % 4 == 0 && ((uintptr_t)dbank & 15) == 0;
-    const dim3 grid((unsigned)((CL / (vec4 ? 4 : 1) + 255) / 256));
+    // taps per thread: the chain over the positions is sequential, so the parallelism is C * L / V threads.  Four taps per thread
+    // (16-byte stores) leave a config-2 bank (384 000 taps per position) with 1 500 waves for 1 024 SIMDs -- half of them carry two
+    // waves, the others one; two taps per thread (3 000 waves) fill them evenly: 129 -> ~100 us.  V = 4 from 4 waves per SIMD on.
+    static const int synth_v = getenv("SS_SYNTH_V") ? atoi(getenv("SS_SYNTH_V")) : 0;
+    const bool big = CL / 4 / 64 >= (int64_t)c->num_cu * 16;
+    const bool vec4 = p->L % 4 == 0 && ((uintptr_t)dbank & 15) == 0 && (synth_v ? synth_v == 4 : big);
+    const bool vec2 = !vec4 && p->L % 2 == 0 && ((uintptr_t)dbank & 7) == 0 && (synth_v ? synth_v == 2 : true);
+    const dim3 grid((unsigned)((CL / (vec4 ? 4 : (vec2 ? 2 : 1)) + 255) / 256));
     if (fast32 && vec4) hipLaunchKernelGGL((k_rir_synth<true, 4>), grid, dim3(256), 0, stream, d, dbank, dpeak);
+    else if (fast32 && vec2) hipLaunchKernelGGL((k_rir_synth<true, 2>), grid, dim3(256), 0, stream, d, dbank, dpeak);
     else if (fast32) hipLaunchKernelGGL((k_rir_synth<true, 1>), grid, dim3(256), 0, stream, d, dbank, dpeak);
     else if (vec4) hipLaunchKernelGGL((k_rir_synth<false, 4>), grid, dim3(256), 0, stream, d, dbank, dpeak);
     else hipLaunchKernelGGL((k_rir_synth<false, 1>), grid, dim3(256), 0, stream, d, dbank, dpeak);
