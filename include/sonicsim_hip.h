@@ -64,7 +64,8 @@ int ss_convolve_moving_f32(const float* x, int64_t T, const float* rirs, int32_t
 /* ---- row V without a host round trip ----------------------------------------------------------
  * By default ss_convolve_moving_f32 validates 0 <= idx[t] <= P-2 before it returns (the reference's fancy index at
  * SonicSim_moving.py:89-90 raises IndexError at the call), which costs one device-to-host copy and a stream synchronisation.
- * With SS_FLAG_DEVICE_PTR | SS_FLAG_ASYNC_PLAN the schedule is planned by a kernel on `stream` and the call only enqueues work:
+ * With SS_FLAG_DEVICE_PTR | SS_FLAG_ASYNC_PLAN the schedule is planned by a kernel on `stream` and the call only enqueues work
+ * (assembly engine, i.e. filters longer than 8192 taps; for shorter filters the flag is ignored and the call validates as usual):
  * filter rows that do not exist then contribute nothing (an entry of -1 still takes its end filter, row 0) and the
  * condition is reported here instead.
  * ss_async_status synchronises `stream`, returns and clears the latched condition of the current device:

@@ -1834,6 +1834,7 @@ int ss_shutdown(void) {
         if (c->consts14) hipFree(c->consts14);
         if (c->mod13) hipModuleUnload(c->mod13);
         for (int i = 0; i < WS_COUNT; ++i) if (c->ws[i]) hipFree(c->ws[i]);
+        if (c->async_status) hipFree(c->async_status);
         for (auto& p : c->ring) { if (p.host) hipHostFree(p.host); if (p.ev) hipEventDestroy(p.ev); }
         for (auto& e : c->evs) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
         for (auto& e : c->ev_pool) hipEventDestroy(e);
