@@ -125,8 +125,7 @@ __global__ __launch_bounds__(256) void k_idx_minmax(const int64_t* __restrict__ 
 // ---------------------------------------------------------------------------------------------
 // Device-side planner of the explicit (idx, w) schedule for the assembly engine (SS_FLAG_ASYNC_PLAN): the task list of plan.h's
 // build_plan + merge_lpt_xcd, produced on the stream from k_idx_minmax's tile bounds -- no copy to the host, no synchronisation.
-// One workgroup of 1024 threads; every stage is a strided loop, so any T / P works (the sort is O(N^2 / 1024): microseconds at
-// BASELINE sizes, milliseconds for hours of audio).  The ORDER of the list only matters for speed (every output sample receives
+// One workgroup of 1024 threads; every stage is a strided loop, so any T / P works.  The ORDER of the list only matters for speed (every output sample receives
 // exactly two float atomics, a commutative sum), so the rule is restated in a form that needs no sequential pass:
 //   * row-tasks (row, j0, nj) in time order; cost as in plan.h; `groups` contiguous ranges of equal total cost (one per XCD);
 //   * inside a range by descending cost (ties in time order), channels of a row-task adjacent;
@@ -145,6 +144,7 @@ struct PlanDevArgs {
     int32_t* rcount;   // [P + 1]
     int32_t* rtask;    // [cap_rows][4]: row, j0, nj, cost
     unsigned long long* keys;   // [cap_rows]
+    int32_t* bins;     // [groups * 4096] counting-sort bins
     int32_t* out;      // header (16 bytes: ntasks, 0, 0, 0) + Task[cap_rows * C]
     int32_t* status;   // [0] code (1 = interp_index out of range, 2 = plan capacity exceeded), [1] tile / count, latched
 };
@@ -164,7 +164,7 @@ __device__ inline long long block_exclusive_scan(T* v, int n, long long* sh /*[1
     long long carry = 0;
     for (int base = 0; base < n; base += nt) {
         const int i = base + tid;
-        const long long x = i < n ? (long long)v[i] : 0;
+        const long long x = i < n ? (long long)__hip_atomic_load(&v[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;   // (entries may have been updated by atomics)
         long long incl = x;
         for (int o = 1; o < 64; o <<= 1) {
             const long long y = __shfl_up(incl, o);
@@ -187,8 +187,8 @@ __device__ inline long long block_exclusive_scan(T* v, int n, long long* sh /*[1
 
 __global__ __launch_bounds__(1024) void k_plan_explicit(PlanDevArgs a) {
     __shared__ long long sh[17];
-    __shared__ unsigned long long tile[1024];
     __shared__ int gcount[64];
+    __shared__ int crange[2];
     const int tid = threadIdx.x, nt = blockDim.x;
     // ---- 1: per output block min/max of idx, range check, clamp
     for (int j = tid; j < a.nblk; j += nt) {
@@ -255,51 +255,56 @@ __global__ __launch_bounds__(1024) void k_plan_explicit(PlanDevArgs a) {
             }
         }
     __syncthreads();
-    // ---- 5: ranges of equal total cost, sort keys
-    for (int i = tid; i < N; i += nt) a.keys[i] = (unsigned long long)a.rtask[4 * (size_t)i + 3];
+    // ---- 5: ranges of equal total cost; counting sort by (range, descending cost) -- O(N + bins)
+    if (tid == 0) { crange[0] = 4095; crange[1] = 0; }
+    __syncthreads();
+    for (int i = tid; i < N; i += nt) {
+        const int c = a.rtask[4 * (size_t)i + 3];
+        a.keys[i] = (unsigned long long)c;
+        atomicMin(&crange[0], c);
+        atomicMax(&crange[1], c);
+    }
+    __syncthreads();
+    int groups = a.groups;
+    if (groups > 8) groups = 8;                          // bins[] holds 8 x 4096 classes
+    if (groups < 1 || (long long)N * a.C < 2LL * groups) groups = 1;
+    const int cmax = crange[1], span = N > 0 ? cmax - crange[0] + 1 : 1;     // only the costs that occur get a bin
+    const int nbins = groups * span;
+    for (int i = tid; i < nbins; i += nt) a.bins[i] = 0;
     __syncthreads();
     const long long total = block_exclusive_scan(a.keys, N, sh);
-    int groups = a.groups;
-    if (groups > 64) groups = 64;
-    if (groups < 1 || (long long)N * a.C < 2LL * groups) groups = 1;
     for (int i = tid; i < N; i += nt) {
         const long long acc = (long long)a.keys[i];
         const int c = a.rtask[4 * (size_t)i + 3];
         int g = total > 0 ? (int)((acc + c / 2) * groups / total) : 0;        // total < 2^43: no overflow with groups <= 64
         if (g >= groups) g = groups - 1;
         atomicAdd(&gcount[g], 1);
-        a.keys[i] = ((unsigned long long)g << 52) | ((unsigned long long)(4095 - c) << 40) | (unsigned long long)i;
+        const int cls = g * span + (cmax - c);
+        atomicAdd(&a.bins[cls], 1);
+        a.keys[i] = ((unsigned long long)g << 32) | (unsigned long long)cls;
     }
     __syncthreads();
-    // ---- 6: rank of every key (keys are unique), then the round-robin position
-    for (int base = 0; base < N; base += nt) {
-        const int i = base + tid;
-        const unsigned long long mine = i < N ? a.keys[i] : 0;
-        int rank = 0;
-        for (int t0 = 0; t0 < N; t0 += 1024) {
-            __syncthreads();
-            if (t0 + tid < N) tile[tid] = a.keys[t0 + tid];
-            __syncthreads();
-            const int m = N - t0 < 1024 ? N - t0 : 1024;
-            for (int k = 0; k < m; ++k) rank += tile[k] < mine ? 1 : 0;
-        }
-        if (i < N) {
-            const int g = (int)(mine >> 52);
-            int gs = 0;
-            for (int q = 0; q < g; ++q) gs += gcount[q];
-            const int32_t* t = a.rtask + 4 * (size_t)i;
-            const long long e0 = (long long)(rank - gs) * a.C;
-            for (int c = 0; c < a.C; ++c) {
-                const long long e = e0 + c;
-                long long pos = 0;
-                for (int q = 0; q < groups; ++q) {
-                    const long long cq = (long long)gcount[q] * a.C;
-                    pos += cq < e ? cq : e;
-                    if (q < g && cq > e) ++pos;
-                }
-                int32_t* o = a.out + 4 + 4 * (size_t)pos;
-                o[0] = t[0]; o[1] = c; o[2] = t[1] << a.rs; o[3] = t[2];
+    block_exclusive_scan(a.bins, nbins, sh);             // start of every (range, cost) class in the sorted order
+    // ---- 6: place every row-task (the order inside a class is whatever the atomics give: equal cost, same range), then the
+    //         round-robin position of each of its C tasks
+    for (int i = tid; i < N; i += nt) {
+        const int cls = (int)(a.keys[i] & 0xffffffffu);
+        const int rank = atomicAdd(&a.bins[cls], 1);
+        const int g = (int)(a.keys[i] >> 32);
+        int gs = 0;
+        for (int q = 0; q < g; ++q) gs += gcount[q];
+        const int32_t* t = a.rtask + 4 * (size_t)i;
+        const long long e0 = (long long)(rank - gs) * a.C;
+        for (int c = 0; c < a.C; ++c) {
+            const long long e = e0 + c;
+            long long pos = 0;
+            for (int q = 0; q < groups; ++q) {
+                const long long cq = (long long)gcount[q] * a.C;
+                pos += cq < e ? cq : e;
+                if (q < g && cq > e) ++pos;
             }
+            int32_t* o = a.out + 4 + 4 * (size_t)pos;
+            o[0] = t[0]; o[1] = c; o[2] = t[1] << a.rs; o[3] = t[2];
         }
     }
     if (tid == 0) { a.out[0] = N * a.C; a.out[1] = 0; a.out[2] = 0; a.out[3] = 0; }
@@ -1593,7 +1598,7 @@ int render(int mode, const float* x, int64_t T, const float* bank, int32_t P, in
         auto al = [](size_t n) { return (n + 255) & ~(size_t)255; };
         const size_t o_lo = 0, o_hi = o_lo + al(4 * (size_t)nblk), o_first = o_hi + al(4 * (size_t)nblk), o_last = o_first + al(4 * (size_t)P),
                      o_rc = o_last + al(4 * (size_t)P), o_rt = o_rc + al(4 * ((size_t)P + 1)), o_keys = o_rt + al(16 * (size_t)cap_rows),
-                     o_end = o_keys + al(8 * (size_t)cap_rows);
+                     o_bins = o_keys + al(8 * (size_t)cap_rows), o_end = o_bins + al(4 * 8 * 4096);
         if ((rc = ws_ensure(c, WS_DPLAN, o_end))) return rc;
         if ((rc = ws_ensure(c, WS_DTASKS, 16 + sizeof(Task) * (size_t)cap_rows * C))) return rc;
         if (!c->async_status) {
@@ -1605,7 +1610,7 @@ int render(int mode, const float* x, int64_t T, const float* bank, int32_t P, in
         pa.bmin = (const int32_t*)c->ws[WS_BMIN]; pa.bmax = (const int32_t*)c->ws[WS_BMAX]; pa.nfine = nfine;
         pa.fine_per_block = BB / DTILE; pa.nblk = nblk; pa.P = P; pa.C = C; pa.jmax = JM; pa.NP = NPart; pa.groups = 8; pa.cap_rows = cap_rows; pa.rs = rs;
         pa.lo = (int32_t*)(base + o_lo); pa.hi = (int32_t*)(base + o_hi); pa.first = (int32_t*)(base + o_first); pa.last = (int32_t*)(base + o_last);
-        pa.rcount = (int32_t*)(base + o_rc); pa.rtask = (int32_t*)(base + o_rt); pa.keys = (unsigned long long*)(base + o_keys);
+        pa.rcount = (int32_t*)(base + o_rc); pa.rtask = (int32_t*)(base + o_rt); pa.keys = (unsigned long long*)(base + o_keys); pa.bins = (int32_t*)(base + o_bins);
         pa.out = dplan_out = (int32_t*)c->ws[WS_DTASKS];
         pa.status = c->async_status;
         hipLaunchKernelGGL(k_plan_explicit, dim3(1), dim3(1024), 0, stream, pa);
