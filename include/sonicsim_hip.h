@@ -165,6 +165,11 @@ int ss_mix_batch_f32(const float* const* speakers, const float* const* noises, i
                      float* gains_out, uint32_t flags, void* stream);
 /* enhancement/look2hear/datas/movingdatamodule.py:34-48 overlap_audio: out[t] = (x[t-d] + x[t+d]) + x[t] with zero fill. */
 int ss_overlap_audio_f32(const float* x, float* out, int64_t T, int64_t delay_samples, uint32_t flags, void* stream);
+/* enhancement/look2hear/datas/movingdatamodule_remix.py:136-146 (the "remix" training item: speech and noise crops summed WITHOUT
+ * level randomisation): out[t] = (first_0[t] + first_1[t] + ...) + (second_0[t] + ...), float32, left to right inside a group like
+ * torch.sum over the stack dimension.  first / second: HOST arrays of device pointers to the crop starts; at most 8 sources in all. */
+int ss_crop_sum_f32(const float* const* first, int32_t n_first, const float* const* second, int32_t n_second, int64_t n, float* out,
+                    uint32_t flags, void* stream);
 
 /* ---- row N3: the source-assembly step before the path -- torchaudio.transforms.Resample(orig_freq=sr, new_freq=sample_rate)
  *      at SonicSim-SonicSet/SonicSim_audio.py:249,297 (44.1 / 48 kHz corpora -> 16 kHz).  PARITY UNPINNED (torchaudio is absent): the

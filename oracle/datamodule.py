@@ -14,7 +14,12 @@ The reference's arithmetic for these rows lives in torch CPU ops (``torch.mean``
 Python ``random`` / torch global RNG streams, so the restatement uses the same primitives -- like ``oracle/moving.py`` uses SciPy.
 File access is replaced by a ``load(relative_path) -> (C, T) float32 ndarray`` callback (the reference calls ``torchaudio.load``).
 
-PINNED: ``tests/test_oracle_golden_aux.py`` checks every function bit-for-bit against ``tests/golden/g10_datamodule.npz``, produced by
+  * ``enhancement/look2hear/datas/movingdatamodule_remix.py``
+        find_overlap_region           :50-76
+        MovingTrainDataset.__getitem__   :96-148   (segment-table crops, speech + noise without level randomisation)
+        MovingTestEvalDataset.__getitem__ :196-240
+
+PINNED: ``tests/test_oracle_golden_aux.py`` checks every function bit-for-bit against ``tests/golden/g10_datamodule.npz`` / ``g12_remix.npz``, produced by
 importing the reference modules unmodified under stubs (``tests/golden/make_golden_aux.py``).
 """
 from __future__ import annotations
@@ -110,6 +115,64 @@ def enh_test_eval_getitem(load, folder, sample_rate=16000, num_spks=0, is_mono=T
     """enh :217-260: clean = moving_audio_{num_spks+1}; noise sum -> overlap_audio(delay 6 s) -> SNR ~ U(-10, 15)."""
     speaker_wavs = _load_stack(load, folder, ["moving_audio_{}.wav".format(num_spks + 1)], is_mono)[0]
     noise_wav = _load_stack(load, folder, ["{}_audio.wav".format(n) for n in _noise_types(noise_type)], is_mono)
+    all_noise = torch.sum(noise_wav, dim=0)
+    all_noise = overlap_audio(all_noise.view(1, -1), sample_rate, delay=6).view(-1)
+    target_refch_energy = compute_mch_rms_dB(speaker_wavs)
+    snr = torch.Tensor(1).uniform_(-10, 15).numpy()
+    noise_refch_energy = compute_mch_rms_dB(all_noise)
+    gain = min(target_refch_energy - noise_refch_energy - snr, 40)
+    all_noise *= 10. ** (gain / 20.)
+    return speaker_wavs + all_noise, speaker_wavs, dict(snr=snr)
+
+
+# ----------------------------------------------------------------------------- the "remix" variant (enhancement/look2hear/datas/movingdatamodule_remix.py)
+def find_overlap_region(data, min_overlap=2, max_overlap=3, max_duration=None, sample_rate=None):
+    """remix :50-76: draw (start, end) inside the span of all 'start_end_points' until between min_overlap and max_overlap of the
+    points have an end inside it (and, oddly, until the region is at least ``max_duration`` long -- kept as written)."""
+    all_points = []
+    for source in data.values():
+        if "start_end_points" in source:
+            all_points.extend(source["start_end_points"])
+    min_start = min(point[0] for point in all_points)
+    max_end = max(point[1] for point in all_points)
+    while True:
+        overlap_start = random.randint(min_start, max_end)
+        overlap_end = random.randint(overlap_start, max_end)
+        if max_duration is not None and sample_rate is not None:
+            if (overlap_end - overlap_start) / sample_rate < max_duration:
+                continue
+        overlap_count = sum(overlap_start <= point[0] <= overlap_end or overlap_start <= point[1] <= overlap_end for point in all_points)
+        if min_overlap <= overlap_count <= max_overlap:
+            return overlap_start, overlap_end
+
+
+def remix_train_getitem(load, json_start_end, sample_rate=16000, is_mono=True, noise_type="noise"):
+    """remix :96-148: a key of the segment table -> one of its two speakers (random.choices, k=1), the noise stems ('noise' through
+    overlap_audio, 6 s), one of the key's (start, end) segments; mix = speech + noise WITHOUT level randomisation."""
+    speech_dir_key = random.choice(list(json_start_end.keys()))
+    speaker_id = [int(i) for i in speech_dir_key.split("/")[-1].split("-")]
+    speech_dir = speech_dir_key[:-4]
+    speaker_id.sort()
+    speaker_id = random.choices(speaker_id, k=1)
+    speaker_wav = _load_stack(load, speech_dir, ["s{}.wav".format(i) for i in speaker_id], is_mono)
+    noise_wavs = []
+    for noise in _noise_types(noise_type):
+        noise_wav = _load_stack(load, speech_dir, ["{}.wav".format(noise)], is_mono)[0]
+        if noise == "noise":
+            noise_wav = overlap_audio(noise_wav.view(1, -1), sample_rate, delay=6).view(-1)
+        noise_wavs.append(noise_wav)
+    noise_wav = torch.stack(noise_wavs)
+    start, end = random.choice(json_start_end[speech_dir_key])
+    speaker_wav = speaker_wav[:, start:end]
+    noise_wav = noise_wav[:, start:end]
+    mix_wav = torch.sum(speaker_wav, dim=0) + torch.sum(noise_wav, dim=0)
+    return mix_wav, speaker_wav.mean(0), dict(key=speech_dir_key, speaker=speaker_id[0], start=start, end=end)
+
+
+def remix_test_eval_getitem(load, folder, sample_rate=16000, num_spks=0, is_mono=True, noise_type="noise"):
+    """remix :196-240: the enhancement test-eval item on files 's{k}.wav' / '{noise}.wav'."""
+    speaker_wavs = _load_stack(load, folder, ["s{}.wav".format(num_spks + 1)], is_mono)[0]
+    noise_wav = _load_stack(load, folder, ["{}.wav".format(n) for n in _noise_types(noise_type)], is_mono)
     all_noise = torch.sum(noise_wav, dim=0)
     all_noise = overlap_audio(all_noise.view(1, -1), sample_rate, delay=6).view(-1)
     target_refch_energy = compute_mch_rms_dB(speaker_wavs)

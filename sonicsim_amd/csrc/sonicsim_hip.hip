@@ -2484,6 +2484,48 @@ int ss_mix_batch_f32(const float* const* speakers, const float* const* noises, i
     return SS_OK;
 }
 
+// enhancement/look2hear/datas/movingdatamodule_remix.py:136-146: crops of resident stems summed without gains --
+// out[t] = (a_0[t] + a_1[t] + ...) + (b_0[t] + b_1[t] + ...), float32, left to right inside a group (torch.sum over the stack dim)
+struct CropSumArgs {
+    const float* src[8];
+    int32_t na, nb;
+};
+
+__global__ __launch_bounds__(256) void k_crop_sum(CropSumArgs a, float* __restrict__ out, int64_t n) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n) return;
+    float sa = a.src[0][t];
+    for (int i = 1; i < a.na; ++i) sa += a.src[i][t];
+    if (a.nb > 0) {
+        float sb = a.src[a.na][t];
+        for (int i = 1; i < a.nb; ++i) sb += a.src[a.na + i][t];
+        sa += sb;
+    }
+    out[t] = sa;
+}
+
+int ss_crop_sum_f32(const float* const* first, int32_t n_first, const float* const* second, int32_t n_second, int64_t n, float* out,
+                    uint32_t flags, void* stream_) {
+    if (!first || !out || n_first < 1 || n_second < 0 || n_first + n_second > 8 || n < 1 || (n_second > 0 && !second))
+        return fail(SS_EINVAL, "bad argument (1..8 sources in all)");
+    if (!(flags & SS_FLAG_DEVICE_PTR)) return fail(SS_EINVAL, "device pointers only (SS_FLAG_DEVICE_PTR)");
+    CropSumArgs a;
+    a.na = n_first;
+    a.nb = n_second;
+    for (int i = 0; i < 8; ++i) a.src[i] = nullptr;
+    for (int i = 0; i < n_first; ++i) { if (!first[i]) return fail(SS_EINVAL, "NULL source"); a.src[i] = first[i]; }
+    for (int i = 0; i < n_second; ++i) { if (!second[i]) return fail(SS_EINVAL, "NULL source"); a.src[n_first + i] = second[i]; }
+    Ctx* c;
+    int rc = get_ctx(&c);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(c->mu);
+    hipStream_t stream = (hipStream_t)stream_;
+    if ((rc = stream_enter(c, stream))) return rc;
+    hipLaunchKernelGGL(k_crop_sum, dim3(grid_for(n)), dim3(256), 0, stream, a, out, n);
+    HIPCHK(hipGetLastError());
+    return SS_OK;
+}
+
 int ss_overlap_audio_f32(const float* x, float* out, int64_t T, int64_t delay_samples, uint32_t flags, void* stream_) {
     if (!x || !out || T < 1 || delay_samples < 0 || x == out) return fail(SS_EINVAL, "bad argument");
     if (!(flags & SS_FLAG_DEVICE_PTR)) return fail(SS_EINVAL, "device pointers only (SS_FLAG_DEVICE_PTR)");

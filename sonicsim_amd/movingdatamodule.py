@@ -12,6 +12,9 @@ with the rendered stems RESIDENT in HBM:
   MovingTrainDataset.get_batch    (extension) B successive items with ONE batched mix launch sequence (ss_mix_batch_f32)
   MovingTestEvalDataset           sep :177-226                whole-length mix of two fixed speakers
   EnhMovingTestEvalDataset        enh :217-260                noise through overlap_audio (6 s), SNR ~ U(-10, 15)
+  find_overlap_region             remix :50-76                (enhancement/look2hear/datas/movingdatamodule_remix.py)
+  RemixMovingTrainDataset         remix :78-148               segment-table crops, speech + noise without level randomisation
+  RemixMovingTestEvalDataset      remix :179-240              the enhancement test-eval item on 's{k}.wav' / '{noise}.wav'
 
 What stays on the host, on purpose: the Python ``random`` draws (folder, speaker ids, crop starts) and the torch-RNG draws
 (SIR, SNR).  Their ORDER is part of the reference's behaviour (``random.seed`` / ``torch.manual_seed`` reproduce an epoch), and the
@@ -177,6 +180,9 @@ class EnhMovingTestEvalDataset:
     """enh :198-260: clean = ``moving_audio_{num_spks+1}``, the noise sum goes through ``overlap_audio`` (6 s) first, SNR ~ U(-10, 15).
     Mono only (the reference's ``all_noise.view(1, -1)`` flattens the channels of a multichannel sum)."""
 
+    speaker_file = "moving_audio_{}.wav"
+    noise_file = "{}_audio.wav"
+
     def __init__(self, speech_dir, sample_rate=16000, num_spks=0, is_mono=True, noise_type="noise", device="cuda", loader=None):
         if not is_mono:
             raise NotImplementedError("the reference's overlap path is only meaningful with is_mono=True")
@@ -190,10 +196,82 @@ class EnhMovingTestEvalDataset:
     def __getitem__(self, idx):
         import torch
         folder = self.data_dirs[idx]
-        clean = self.cache.get(folder, "moving_audio_{}.wav".format(self.num_spks + 1), True)
-        noises = [self.cache.get(folder, "{}_audio.wav".format(n), True) for n in _noise_types(self.noise_type)]
+        clean = self.cache.get(folder, self.speaker_file.format(self.num_spks + 1), True)
+        noises = [self.cache.get(folder, self.noise_file.format(n), True) for n in _noise_types(self.noise_type)]
         all_noise = noises[0] if len(noises) == 1 else noises[0] + noises[1]                  # torch.sum over the stack (enh :240)
         all_noise = overlap_audio(all_noise.view(1, -1), self.sample_rate, delay=6).view(-1)  # enh :243
         snr = torch.Tensor(1).uniform_(-10, 15).numpy()                                        # enh :247 / :254
         mix, out, _ = ops.mix_batch([[(clean, 0)]], [[(all_noise, 0)]], clean.shape[-1], np.zeros((1, 0), np.float32), snr)
         return mix[0], out[0, 0], os.path.join(folder)
+
+
+# ----------------------------------------------------------------------------- the "remix" variant
+def find_overlap_region(data, min_overlap=2, max_overlap=3, max_duration=None, sample_rate=None):
+    """enhancement/look2hear/datas/movingdatamodule_remix.py:50-76 (host logic on the Python ``random`` stream, kept as written:
+    ``max_duration`` is a LOWER bound on the region's length there)."""
+    points = [p for source in data.values() if "start_end_points" in source for p in source["start_end_points"]]
+    lo = min(p[0] for p in points)
+    hi = max(p[1] for p in points)
+    while True:
+        start = random.randint(lo, hi)
+        end = random.randint(start, hi)
+        if max_duration is not None and sample_rate is not None and (end - start) / sample_rate < max_duration:
+            continue
+        if min_overlap <= sum(start <= p[0] <= end or start <= p[1] <= end for p in points) <= max_overlap:
+            return start, end
+
+
+class RemixMovingTrainDataset:
+    """movingdatamodule_remix.py:78-148: items are cut at the (start, end) segments of a table (``segments``: the dict of
+    ``./tests/segment-train.json`` or a path to it; key '<folder>/<a>-<b>' -> list of [start, end]); one of the key's two speakers, the
+    noise stems ('noise' through ``overlap_audio``, 6 s), mix = speech + noise with NO level randomisation (``ss_crop_sum_f32``).
+    Mono only: with ``is_mono=False`` the reference's ``[:, start:end]`` would slice the channel axis of its (1, C, T) stack."""
+
+    def __init__(self, speech_dir, sample_rate=16000, duration=4.0, num_samples=1000, num_spks=2, is_mono=True, noise_type="noise",
+                 segments="./tests/segment-train.json", device="cuda", loader=None, cache_folders=64):
+        import json
+        if not is_mono:
+            raise NotImplementedError("the reference's remix item is only meaningful with is_mono=True")
+        self.data_dirs = find_bottom_directories(speech_dir)
+        self.sample_rate, self.duration, self.num_samples = sample_rate, duration, num_samples
+        self.num_spks, self.noise_type = num_spks, noise_type
+        if isinstance(segments, dict):
+            self.json_start_end = segments
+        else:
+            with open(segments, "r") as f:
+                self.json_start_end = json.load(f)
+        self.cache = _StemCache(device, loader, cache_folders * 8)
+        self._overlapped: dict = {}
+
+    def __len__(self):
+        return self.num_samples
+
+    def _noise(self, folder, name):
+        t = self.cache.get(folder, "{}.wav".format(name), True)
+        if name != "noise":
+            return t
+        o = self._overlapped.get(folder)                       # (the overlapped noise of a folder is reused like the stems)
+        if o is None:
+            o = overlap_audio(t.view(1, -1), self.sample_rate, delay=6).view(-1)      # remix :125
+            if len(self._overlapped) >= 64:
+                self._overlapped.pop(next(iter(self._overlapped)))
+            self._overlapped[folder] = o
+        return o
+
+    def __getitem__(self, idx):
+        key = random.choice(list(self.json_start_end.keys()))                                  # :97
+        speaker_id = sorted(int(i) for i in key.split("/")[-1].split("-"))                     # :99-101
+        folder = key[:-4]
+        speaker_id = random.choices(speaker_id, k=1)                                           # :102
+        spk = self.cache.get(folder, "s{}.wav".format(speaker_id[0]), True)
+        noises = [self._noise(folder, n) for n in _noise_types(self.noise_type)]
+        start, end = random.choice(self.json_start_end[key])                                   # :130-132
+        n = min(end, spk.shape[0]) - start
+        mix = ops.crop_sum([(spk, start)], [(t, start) for t in noises], n)                    # :139-143
+        return mix, spk[start:start + n]                                                       # speaker_wav.mean(0) of a (1, n) stack
+
+
+class RemixMovingTestEvalDataset(EnhMovingTestEvalDataset):
+    """movingdatamodule_remix.py:179-240: the enhancement test-eval item on files 's{k}.wav' / '{noise}.wav'."""
+    speaker_file = "s{}.wav"
+    noise_file = "{}.wav"

@@ -526,6 +526,27 @@ def mix_batch(speaker_crops, noise_crops, n, sirs, snrs, want_gains=False):
     return mix, spk_out, gains
 
 
+def crop_sum(first, second, n):
+    """movingdatamodule_remix.py:136-146: ``sum(first crops) + sum(second crops)`` without gains.  first / second: lists of
+    (tensor (T,), start) on one device; returns (n,) float32."""
+    import torch
+    items = list(first) + list(second)
+    if not first or len(items) > 8:
+        raise ValueError("1..8 sources in all, at least one in the first group")
+    dev = items[0][0].device
+    for t, st in items:
+        if not (_is_dev(t) and t.dtype == torch.float32 and t.ndim == 1 and t.is_contiguous() and t.device == dev):
+            raise ValueError("sources must be contiguous 1-D float32 tensors on one device")
+        if st < 0 or st + n > t.shape[0]:
+            raise ValueError("crop [start, start + n) outside a source")
+    pa = (ctypes.c_void_p * len(first))(*[t.data_ptr() + 4 * int(st) for t, st in first])
+    pb = (ctypes.c_void_p * max(1, len(second)))(*([t.data_ptr() + 4 * int(st) for t, st in second] or [0]))
+    out = torch.empty(n, dtype=torch.float32, device=dev)
+    _set_device(items[0][0])
+    _lib.check(_lib.load().ss_crop_sum_f32(pa, len(first), pb, len(second), int(n), _ptr(out), _lib.FLAG_DEVICE_PTR, _stream_ptr(out)))
+    return out
+
+
 def overlap_audio(x, delay_samples):
     """enhancement/look2hear/datas/movingdatamodule.py:34-48 on a (T,) or (1, T) float32 device tensor."""
     import torch

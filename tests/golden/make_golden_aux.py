@@ -277,10 +277,74 @@ def golden_assembly():
     np.savez_compressed(os.path.join(HERE, "g11_assembly.npz"), **out)
 
 
+# ------------------------------------------------------------------------------------------------ row N2, "remix" variant
+def golden_remix():
+    """enhancement/look2hear/datas/movingdatamodule_remix.py: find_overlap_region (:50-76), MovingTrainDataset.__getitem__ (:96-148),
+    MovingTestEvalDataset.__getitem__ (:196-240).  The train dataset opens ./tests/segment-train.json relative to the working directory."""
+    import json
+    ta = datamodule_stubs()
+    T, C = 48000, 2
+    root = tempfile.mkdtemp(prefix="ssgold_")
+    folders = ["train/roomA/m1", "train/roomB/m2"]
+    make_tree(root, folders + ["tests", "eval/roomC/e1"])
+
+    def load(path):
+        return torch.from_numpy(golden_stem(os.path.relpath(path, root), C, T)), 16000
+
+    ta.load = load
+    # keys: '<folder>/<a>-<b>' (the item strips the last four characters to get the folder); values: [start, end] pairs
+    segs = {os.path.join(root, folders[0]) + "/1-2": [[1000, 17000], [20000, 30000], [5, 4005]],
+            os.path.join(root, folders[1]) + "/2-3": [[0, 48000], [31000, 47000]]}
+    with open(os.path.join(root, "tests", "segment-train.json"), "w") as f:
+        json.dump(segs, f)
+    cwd = os.getcwd()
+    os.chdir(root)
+    try:
+        rmx = load_module("ref_enh_remix", os.path.join(REF, "enhancement/look2hear/datas/movingdatamodule_remix.py"))
+        out = {"T": T, "C": C, "folders": np.array(folders), "seg_keys": np.array([os.path.relpath(k, root) for k in segs]),
+               "seg_json": json.dumps({os.path.relpath(k, root): v for k, v in segs.items()})}
+        cases = [("noise", 7, 17), ("all", 8, 18), ("music", 9, 19), ("noise", 10, 20)]
+        for i, (nt, ps, ts) in enumerate(cases):
+            ds = rmx.MovingTrainDataset(os.path.join(root, "train"), 16000, 4.0, 10, 2, True, nt)
+            random.seed(ps)
+            torch.manual_seed(ts)
+            mix, spk = ds[0]
+            out[f"tr_cfg{i}"] = np.array([{"noise": 0, "music": 1, "all": 2}[nt], ps, ts])
+            out[f"tr_mix{i}"] = mix.numpy()
+            out[f"tr_spk{i}"] = spk.numpy()
+            out[f"tr_next{i}"] = random.random()                      # position of the Python random stream after the item
+        out["tr_n"] = len(cases)
+        # find_overlap_region
+        data = {"a": {"start_end_points": [[100, 900], [2000, 5000], [7000, 7100]]}, "b": {"start_end_points": [[400, 2500], [6000, 9000]]},
+                "c": {"other": 1}}
+        fo = []
+        for j, (kw, seed) in enumerate([(dict(), 1), (dict(min_overlap=1, max_overlap=2), 2), (dict(min_overlap=2, max_overlap=4, max_duration=0.1, sample_rate=16000), 3),
+                                        (dict(min_overlap=3, max_overlap=3), 4)]):
+            random.seed(seed)
+            a, b = rmx.find_overlap_region(data, **kw)
+            fo.append([a, b])
+            out[f"fo_next{j}"] = random.random()
+        out["fo_out"] = np.array(fo, dtype=np.int64)
+        out["fo_data"] = json.dumps(data)
+        # test-eval item (file names 's{k}.wav', '{noise}.wav')
+        for j, nt in enumerate(["noise", "all"]):
+            ds = rmx.MovingTestEvalDataset(os.path.join(root, "eval"), 16000, 1, True, nt)
+            torch.manual_seed(71 + j)
+            mix, spk, folder = ds[0]
+            out[f"ev_mix{j}"] = mix.numpy()
+            out[f"ev_spk{j}"] = spk.numpy()
+        out["ev_folder"] = os.path.relpath(folder, root)
+    finally:
+        os.chdir(cwd)
+        shutil.rmtree(root)
+    np.savez_compressed(os.path.join(HERE, "g12_remix.npz"), **out)
+
+
 def main():
     golden_rir_combination()
     golden_datamodules()
     golden_assembly()
+    golden_remix()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))

@@ -72,3 +72,19 @@ def test_find_bottom_directories(tmp_path):
     for d in ("a/x/1", "a/x/2", "a/y", "b"):
         os.makedirs(tmp_path / d)
     assert sorted(os.path.relpath(p, tmp_path) for p in find_bottom_directories(str(tmp_path))) == ["a/x/1", "a/x/2", "a/y", "b"]
+
+
+def test_remix_find_overlap_region_replays_reference_golden():
+    """movingdatamodule_remix.py:50-76 through the PRODUCT's host function: same draws, same stream position afterwards"""
+    import json
+    import random
+    from sonicsim_amd import movingdatamodule as M
+    from util import golden
+    g = golden("g12_remix.npz")
+    data = json.loads(str(g["fo_data"]))
+    kws = [dict(), dict(min_overlap=1, max_overlap=2), dict(min_overlap=2, max_overlap=4, max_duration=0.1, sample_rate=16000),
+           dict(min_overlap=3, max_overlap=3)]
+    for j, kw in enumerate(kws):
+        random.seed(j + 1)
+        assert list(M.find_overlap_region(data, **kw)) == list(g["fo_out"][j])
+        assert random.random() == float(g[f"fo_next{j}"])

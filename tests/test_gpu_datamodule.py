@@ -127,3 +127,33 @@ def test_crop_energy_and_mono_fold(gpu):
     assert ops.crop_rms_db([z], [0], 1000)[0, 0] == -200.0
     with pytest.raises(ValueError):
         ops.crop_rms_db([z], [1], 1000)
+
+
+def test_remix_variant_replays_reference_goldens(gpu, tmp_path):
+    """enhancement/look2hear/datas/movingdatamodule_remix.py: train items (:96-148; sums without gains: bit for bit, incl. the random
+    stream position) and the test-eval item (:196-240) through the product's classes"""
+    import json
+    from sonicsim_amd import movingdatamodule as M
+    g = golden("g12_remix.npz")
+    C, T = int(g["C"]), int(g["T"])
+    root = str(tmp_path)
+    _tree(tmp_path, list(g["folders"]) + [str(g["ev_folder"])])
+    segs = {os.path.join(root, k): v for k, v in json.loads(str(g["seg_json"])).items()}
+    ld = _loader(root, C, T)
+    for i in range(int(g["tr_n"])):
+        nt, ps, ts = (int(v) for v in g[f"tr_cfg{i}"])
+        ds = M.RemixMovingTrainDataset(os.path.join(root, "train"), 16000, 4.0, 10, 2, True, NOISE[nt], segments=segs, device=gpu, loader=ld)
+        random.seed(ps)
+        torch.manual_seed(ts)
+        mix, spk = ds[0]
+        assert np.array_equal(mix.cpu().numpy(), g[f"tr_mix{i}"]) and np.array_equal(spk.cpu().numpy(), g[f"tr_spk{i}"]), i
+        assert random.random() == float(g[f"tr_next{i}"])
+    with pytest.raises(NotImplementedError):
+        M.RemixMovingTrainDataset(root, is_mono=False, segments=segs, device=gpu, loader=ld)
+    folder = os.path.join(root, str(g["ev_folder"]))
+    for j, nt in enumerate(["noise", "all"]):
+        ev = M.RemixMovingTestEvalDataset(os.path.join(root, "eval"), 16000, 1, True, nt, device=gpu, loader=ld)
+        ev.data_dirs = [folder]
+        torch.manual_seed(71 + j)
+        mix, clean, where = ev[0]
+        assert where == folder and np.array_equal(clean.cpu().numpy(), g[f"ev_spk{j}"]) and rel_rms(mix.cpu().numpy(), g[f"ev_mix{j}"]) < 1e-6

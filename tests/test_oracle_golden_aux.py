@@ -108,3 +108,44 @@ def test_enh_items_bitwise():
     torch.manual_seed(61)
     mix, spk, _ = D.enh_test_eval_getitem(_loader(g), str(g["ev_folder"]), 16000, 0, True, "noise")
     assert np.array_equal(mix.numpy(), g["enh_ev_mix"]) and np.array_equal(spk.numpy(), g["enh_ev_spk"])
+
+
+# ------------------------------------------------------------------------------------------------ row N2, "remix" variant (g12)
+def _remix_env(g):
+    import json
+    C, T = int(g["C"]), int(g["T"])
+    segs = json.loads(str(g["seg_json"]))                # keys relative to the dataset root, exactly the layout the golden run used
+
+    def load(path):
+        return golden_stem(path, C, T)
+    return segs, load
+
+
+def test_remix_train_items_bitwise():
+    """enhancement/look2hear/datas/movingdatamodule_remix.py:96-148, incl. the position of the Python random stream afterwards"""
+    g = golden("g12_remix.npz")
+    segs, load = _remix_env(g)
+    for i in range(int(g["tr_n"])):
+        nt, ps, ts = (int(v) for v in g[f"tr_cfg{i}"])
+        random.seed(ps)
+        torch.manual_seed(ts)
+        mix, spk, info = D.remix_train_getitem(load, segs, 16000, True, {0: "noise", 1: "music", 2: "all"}[nt])
+        assert np.array_equal(mix.numpy(), g[f"tr_mix{i}"]) and np.array_equal(spk.numpy(), g[f"tr_spk{i}"]), (i, info)
+        assert random.random() == float(g[f"tr_next{i}"])
+
+
+def test_remix_find_overlap_region_and_eval_bitwise():
+    import json
+    g = golden("g12_remix.npz")
+    data = json.loads(str(g["fo_data"]))
+    kws = [dict(), dict(min_overlap=1, max_overlap=2), dict(min_overlap=2, max_overlap=4, max_duration=0.1, sample_rate=16000),
+           dict(min_overlap=3, max_overlap=3)]
+    for j, kw in enumerate(kws):
+        random.seed(j + 1)
+        assert list(D.find_overlap_region(data, **kw)) == list(g["fo_out"][j])
+        assert random.random() == float(g[f"fo_next{j}"])
+    _, load = _remix_env(g)
+    for j, nt in enumerate(["noise", "all"]):
+        torch.manual_seed(71 + j)
+        mix, spk, _ = D.remix_test_eval_getitem(load, str(g["ev_folder"]), 16000, 1, True, nt)
+        assert np.array_equal(mix.numpy(), g[f"ev_mix{j}"]) and np.array_equal(spk.numpy(), g[f"ev_spk{j}"])
