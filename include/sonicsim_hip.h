@@ -125,6 +125,14 @@ int ss_rir_bank_synth_peak_f32(const SsRirParams* prm, float* bank, float* peak,
  * it synchronises the stream.  Degenerate banks behave like the reference: an all-zero bank becomes NaN (0/0), a NaN anywhere
  * makes everything NaN. */
 int ss_peak_normalize_f32(float* data, int64_t n, float* peak_out, uint32_t flags, void* stream);
+/* Row R, optional ("a geometric RIR model richer than K1 behind render_ir"): image-source early reflections of a
+ * shoebox room [0, room] added onto bank[P][C][L] (device pointer).  src[P][3], mic[C][3] (metres, inside the box), pat[P][C] (channel
+ * pattern of the direct path), room[3]: HOST arrays.  Every image with 1..order wall reflections contributes
+ * pat * beta^reflections / max(d, 0.1) at the fractional delay fs * d / 343, split linearly over the two neighbouring taps (the first
+ * min(L, 16384) taps).  Content is synthetic by definition (oracle/rir_synth.py::early_reflections); order 0 is a no-op. */
+int ss_rir_early_add_f32(float* bank, int32_t P, int32_t C, int32_t L, float fs, const float* src, const float* mic, const float* pat,
+                         const float* room, float beta, int32_t order, uint32_t flags, void* stream);
+
 /* data /= *divisor with a divisor that is already known (ss_rir_bank_synth_peak_f32): the single pass that materialises the
  * normalised bank of SonicSim_audio.py:398 when the caller wants the bank itself (SonicSet.py:68 saves it).  `divisor`
  * follows flags bit 0.  Same IEEE division, same bits as ss_peak_normalize_f32. */

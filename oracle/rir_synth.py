@@ -84,6 +84,43 @@ def rir_bank_synth(delay, dgain, L, fs, rt60, seed, tail_gain=0.05, rho=0.9):
     return bank
 
 
+def early_reflections(src, mic, pat, room, beta, order, L, fs, wmax=16384, c_sound=343.0):
+    """NumPy DEFINITION of the optional image-source early part ("a geometric RIR model richer than K1
+    behind render_ir"; synthetic, parity unpinned like the rest of row R).  Shoebox [0, room]; for source position p and microphone c
+    every image  (1 - 2 q) * src_p + 2 n * room,  n in [-order, order]^3, q in {0, 1}^3,  with 1 <= reflections <= order
+    (reflections = sum over the axes of |n - q| + |n|, Allen & Berkley) adds
+        pat[p, c] * beta^reflections / max(d, 0.1)     at the fractional delay fs * d / c_sound,
+    split linearly over the two neighbouring taps; taps from min(L, wmax) on are left alone.  Returns (P, C, L) float64."""
+    src = np.asarray(src, dtype=np.float32).astype(np.float64).reshape(-1, 3)
+    mic = np.asarray(mic, dtype=np.float32).astype(np.float64).reshape(-1, 3)
+    pat = np.asarray(pat, dtype=np.float32).astype(np.float64)
+    room = np.asarray(room, dtype=np.float32).astype(np.float64).reshape(3)
+    P, C = src.shape[0], mic.shape[0]
+    W = min(L, wmax)
+    out = np.zeros((P, C, L), dtype=np.float64)
+    rng1 = range(-order, order + 1)
+    for nx in rng1:
+        for ny in rng1:
+            for nz in rng1:
+                for qx in (0, 1):
+                    for qy in (0, 1):
+                        for qz in (0, 1):
+                            refl = abs(nx - qx) + abs(nx) + abs(ny - qy) + abs(ny) + abs(nz - qz) + abs(nz)
+                            if refl < 1 or refl > order:
+                                continue
+                            img = src * np.array([1 - 2 * qx, 1 - 2 * qy, 1 - 2 * qz]) + 2.0 * np.array([nx, ny, nz]) * room      # (P, 3)
+                            d = np.maximum(np.linalg.norm(img[:, None, :] - mic[None, :, :], axis=2), 0.1)                     # (P, C)
+                            tau = fs * d / c_sound
+                            i0 = np.floor(tau).astype(np.int64)
+                            fr = tau - i0
+                            g = pat * beta ** refl / d
+                            ok = i0 + 1 < W
+                            pp, cc = np.nonzero(ok)
+                            np.add.at(out, (pp, cc, i0[ok]), (g * (1 - fr))[ok])
+                            np.add.at(out, (pp, cc, i0[ok] + 1), (g * fr)[ok])
+    return out
+
+
 # ----------------------------------------------------------------------------- row G
 def clip_all(audio_list):
     """SonicSim_audio.py:111-127: clip every IR to the shortest."""

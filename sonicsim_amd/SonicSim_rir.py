@@ -102,6 +102,29 @@ def _channel_geometry(src, rcv, rotation, channel_type, channel_order, mic_array
     raise ValueError(f"unknown channel_type {channel_type!r}")
 
 
+def room_box(room: str):
+    """Deterministic shoebox of a room id for the optional early reflections: dimensions ~ U(4, 9) x U(2.6, 3.6) x U(4, 9) m and a
+    wall reflection coefficient ~ U(0.6, 0.9) from the room seed (x right, y up, z front)."""
+    seed = zlib.crc32(("box:" + str(room)).encode("utf-8")) & 0xFFFFFFFF
+    r = np.random.default_rng(seed)
+    return np.array([r.uniform(4, 9), r.uniform(2.6, 3.6), r.uniform(4, 9)]), float(r.uniform(0.6, 0.9))
+
+
+def add_early_reflections(bank, room, sources, receiver, pat, sample_rate, order, mic_offsets=None):
+    """Extension: image-source reflections up to ``order`` of the room's shoebox, added on the device to a
+    bank (P, C, L) whose P rows are the source positions ``sources`` (P, 3) heard at ``receiver`` (3,) (+ ``mic_offsets`` (C, 3)).
+    The box is centred on the receiver in x / z and has its floor 1.5 m below it; sources outside are clamped onto its walls.
+    A peak tracked by the generator (``return_peak=True``) is stale afterwards: normalise with ``ops.peak_normalize_`` (it re-measures)."""
+    dims, beta = room_box(room)
+    rcv = np.asarray(receiver, dtype=np.float64).reshape(3)
+    origin = rcv - np.array([dims[0] / 2, 1.5, dims[2] / 2])
+    C = bank.shape[1]
+    off = np.zeros((C, 3)) if mic_offsets is None else np.asarray(mic_offsets, dtype=np.float64).reshape(C, 3)
+    mic = np.clip(rcv[None, :] + off - origin, 0.05, dims - 0.05)
+    src = np.clip(np.asarray(sources, dtype=np.float64).reshape(-1, 3) - origin, 0.05, dims - 0.05)
+    return ops.rir_early_add_(bank, src, mic, pat, dims, beta, order, sample_rate)
+
+
 def _render_batch(room, sources, receivers, rotations, sample_rate, channel_type, channel_order, mic_array, device):
     seed, rt60, length = room_acoustics(room, sample_rate)
     dist, pat = [], []

@@ -67,6 +67,8 @@ _SIGS = {
     "ss_mix_batch_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
                                         ctypes.c_int64, ctypes.c_int64, c_f32p, c_f32p, ctypes.c_void_p, ctypes.c_void_p, c_f32p,
                                         ctypes.c_uint32, ctypes.c_void_p]),
+    "ss_rir_early_add_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_float, ctypes.c_void_p,
+                                            ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_float, ctypes.c_int32, ctypes.c_uint32, ctypes.c_void_p]),
     "ss_crop_sum_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p,
                                        ctypes.c_uint32, ctypes.c_void_p]),
     "ss_overlap_audio_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_uint32, ctypes.c_void_p]),

@@ -2484,6 +2484,89 @@ int ss_mix_batch_f32(const float* const* speakers, const float* const* noises, i
     return SS_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Row R, optional: image-source early reflections of a shoebox room added onto a synthetic bank (SURVEY.md section 8f, N4's second
+// half -- "a geometric RIR model richer than K1 behind render_ir"; content is synthetic by definition, oracle/rir_synth.py::early_reflections).
+// For source position p and microphone c, every image (n in [-N, N]^3, q in {0,1}^3) with 1 <= reflections <= N contributes
+//   g = pat[p][c] * beta^reflections / max(d, 0.1),  d = |(1 - 2q) * src_p + 2 n * room - mic_c|,  at the fractional delay fs * d / 343,
+// split linearly over the two neighbouring taps.  One workgroup per (p, c): the images are scattered into an LDS window in FIXED POINT
+// (integer atomics commute: the result does not depend on the order), then added to the bank by one writer per tap.
+struct EarlyArgs {
+    const float* src;    // [P][3]
+    const float* mic;    // [C][3]
+    const float* pat;    // [P][C]
+    float room[3];
+    float beta, fs;
+    int32_t P, C, L, order, W;
+};
+
+constexpr int EARLY_WMAX = 16384;
+constexpr float EARLY_SCALE = 262144.0f;      // 2^18
+
+__global__ __launch_bounds__(256) void k_rir_early(EarlyArgs a, float* __restrict__ bank) {
+    __shared__ int win[EARLY_WMAX];
+    const int p = blockIdx.x / a.C, c = blockIdx.x % a.C;
+    for (int t = threadIdx.x; t < a.W; t += 256) win[t] = 0;
+    __syncthreads();
+    const float sx = a.src[3 * p], sy = a.src[3 * p + 1], sz = a.src[3 * p + 2];
+    const float mx = a.mic[3 * c], my = a.mic[3 * c + 1], mz = a.mic[3 * c + 2];
+    const float g0 = a.pat[(int64_t)p * a.C + c];
+    const int K = 2 * a.order + 1, nimg = K * K * K * 8;
+    for (int i = threadIdx.x; i < nimg; i += 256) {
+        const int q = i & 7, m = i >> 3;
+        const int nx = m % K - a.order, ny = (m / K) % K - a.order, nz = m / (K * K) - a.order;
+        const int qx = q & 1, qy = (q >> 1) & 1, qz = q >> 2;
+        const int refl = abs(nx - qx) + abs(nx) + abs(ny - qy) + abs(ny) + abs(nz - qz) + abs(nz);
+        if (refl < 1 || refl > a.order) continue;
+        const float dx = (1 - 2 * qx) * sx + 2.0f * nx * a.room[0] - mx;
+        const float dy = (1 - 2 * qy) * sy + 2.0f * ny * a.room[1] - my;
+        const float dz = (1 - 2 * qz) * sz + 2.0f * nz * a.room[2] - mz;
+        const float d = fmaxf(sqrtf(dx * dx + dy * dy + dz * dz), 0.1f);
+        const float tau = a.fs * d / 343.0f;
+        const int i0 = (int)floorf(tau);
+        if (i0 + 1 >= a.W) continue;
+        const float fr = tau - (float)i0;
+        const float g = g0 * powf(a.beta, (float)refl) / d;
+        atomicAdd(&win[i0], (int)lrintf(g * (1.0f - fr) * EARLY_SCALE));
+        atomicAdd(&win[i0 + 1], (int)lrintf(g * fr * EARLY_SCALE));
+    }
+    __syncthreads();
+    float* row = bank + ((int64_t)p * a.C + c) * a.L;
+    for (int t = threadIdx.x; t < a.W; t += 256)
+        if (win[t]) row[t] += (float)win[t] * (1.0f / EARLY_SCALE);
+}
+
+int ss_rir_early_add_f32(float* bank, int32_t P, int32_t C, int32_t L, float fs, const float* src, const float* mic, const float* pat,
+                         const float* room, float beta, int32_t order, uint32_t flags, void* stream_) {
+    if (!bank || !src || !mic || !pat || !room || P < 1 || C < 1 || L < 2 || !(fs > 0) || order < 0 || order > 6 || !(beta >= 0) || beta > 1 ||
+        !(room[0] > 0) || !(room[1] > 0) || !(room[2] > 0))
+        return fail(SS_EINVAL, "bad argument (order 0..6, 0 <= beta <= 1, positive room dimensions)");
+    if (!(flags & SS_FLAG_DEVICE_PTR)) return fail(SS_EINVAL, "the bank must be a device pointer (SS_FLAG_DEVICE_PTR); src / mic / pat / room are host arrays");
+    if (order == 0) return SS_OK;
+    Ctx* c;
+    int rc = get_ctx(&c);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(c->mu);
+    hipStream_t stream = (hipStream_t)stream_;
+    if ((rc = stream_enter(c, stream))) return rc;
+    const size_t nb = sizeof(float) * ((size_t)3 * P + (size_t)3 * C + (size_t)P * C);
+    std::vector<float> host((size_t)3 * P + (size_t)3 * C + (size_t)P * C);
+    memcpy(host.data(), src, sizeof(float) * 3 * P);
+    memcpy(host.data() + 3 * (size_t)P, mic, sizeof(float) * 3 * C);
+    memcpy(host.data() + 3 * (size_t)P + 3 * (size_t)C, pat, sizeof(float) * (size_t)P * C);
+    void* dmeta;
+    if ((rc = upload_small(c, WS_META, host.data(), nb, stream, &dmeta))) return rc;
+    EarlyArgs a;
+    a.src = (const float*)dmeta;
+    a.mic = a.src + 3 * (size_t)P;
+    a.pat = a.mic + 3 * (size_t)C;
+    a.room[0] = room[0]; a.room[1] = room[1]; a.room[2] = room[2];
+    a.beta = beta; a.fs = fs; a.P = P; a.C = C; a.L = L; a.order = order; a.W = L < EARLY_WMAX ? L : EARLY_WMAX;
+    hipLaunchKernelGGL(k_rir_early, dim3((unsigned)((int64_t)P * C)), dim3(256), 0, stream, a, bank);
+    HIPCHK(hipGetLastError());
+    return SS_OK;
+}
+
 // enhancement/look2hear/datas/movingdatamodule_remix.py:136-146: crops of resident stems summed without gains --
 // out[t] = (a_0[t] + a_1[t] + ...) + (b_0[t] + b_1[t] + ...), float32, left to right inside a group (torch.sum over the stack dim)
 struct CropSumArgs {

@@ -236,6 +236,23 @@ def rir_bank_synth(delay, dgain, L, fs, rt60, seed, tail_gain=0.05, rho=0.9, dev
     return bank
 
 
+def rir_early_add_(bank, src, mic, pat, room, beta, order, fs):
+    """Row R, optional: image-source early reflections of the shoebox ``room`` (3,) added in place onto the device bank (P, C, L).
+    src (P, 3), mic (C, 3) in metres inside the box, pat (P, C) channel pattern; 1..order reflections with wall coefficient beta."""
+    import torch
+    if not (_is_dev(bank) and bank.dtype == torch.float32 and bank.ndim == 3 and bank.is_contiguous()):
+        raise ValueError("bank must be a contiguous float32 device tensor (P, C, L)")
+    P, C, L = bank.shape
+    src = np.ascontiguousarray(np.asarray(src, dtype=np.float32).reshape(P, 3))
+    mic = np.ascontiguousarray(np.asarray(mic, dtype=np.float32).reshape(C, 3))
+    pat = np.ascontiguousarray(np.asarray(pat, dtype=np.float32).reshape(P, C))
+    room = np.ascontiguousarray(np.asarray(room, dtype=np.float32).reshape(3))
+    _set_device(bank)
+    _lib.check(_lib.load().ss_rir_early_add_f32(_ptr(bank), P, C, L, float(fs), _ptr(src), _ptr(mic), _ptr(pat), _ptr(room), float(beta), int(order),
+                                                _lib.FLAG_DEVICE_PTR, _stream_ptr(bank)))
+    return bank
+
+
 def peak_normalize_(a, want_peak=False, check=False):
     """Row G (SonicSim_audio.py:398): in-place a /= abs(a).max().  Returns the peak if asked.
     Degenerate banks behave exactly like the reference's torch expression: an all-zero bank turns into NaN (0/0) and a NaN

@@ -270,3 +270,49 @@ def test_fft_conv_odd_and_even_lengths(gpu):
             assert rel_rms(got.cpu().numpy(), want) < 1e-5, (T, L, (T + L - 1) % 2)
     y = A.fft_conv(torch.from_numpy(x).to(gpu), torch.from_numpy(h).to(gpu), is_cpu=True)
     assert not y.is_cuda                                                          # is_cpu=True detaches to the host like the reference
+
+
+def test_early_reflections_against_their_definition(gpu):
+    """optional image-source early part (N4's second half): k_rir_early against oracle/rir_synth.py::early_reflections; the
+    fixed-point scatter is order independent, so two runs agree bit for bit"""
+    import torch
+    from oracle import rir_synth as R
+    from sonicsim_amd import ops
+    rng = np.random.default_rng(21)
+    P, C, L, fs = 7, 3, 6000, 16000
+    room = np.array([6.2, 3.1, 4.7])
+    src = rng.uniform(0.3, 1.0, (P, 3)) * room * 0.9
+    mic = rng.uniform(0.3, 0.7, (C, 3)) * room
+    pat = rng.uniform(-1, 1, (P, C))
+    for order in (1, 2, 3):
+        base = rng.standard_normal((P, C, L)).astype(np.float32) * 1e-3
+        bank = torch.from_numpy(base.copy()).to(gpu)
+        ops.rir_early_add_(bank, src, mic, pat, room, 0.8, order, fs)
+        want = base.astype(np.float64) + R.early_reflections(src, mic, pat, room, 0.8, order, L, fs)
+        got = bank.cpu().numpy()
+        assert np.abs(got - want).max() <= 2e-5 * max(1.0, np.abs(want).max()), order
+        again = torch.from_numpy(base.copy()).to(gpu)
+        ops.rir_early_add_(again, src, mic, pat, room, 0.8, order, fs)
+        assert torch.equal(again, bank)
+    assert (np.abs(want - base) > 1e-4).sum() > 100                  # (order 3 places a few hundred impulses per pair)
+    untouched = torch.from_numpy(base.copy()).to(gpu)
+    ops.rir_early_add_(untouched, src, mic, pat, room, 0.8, 0, fs)   # order 0: no-op
+    assert np.array_equal(untouched.cpu().numpy(), base)
+    with pytest.raises(ValueError):
+        ops.rir_early_add_(untouched, src, mic, pat, room, 1.5, 2, fs)
+
+
+def test_provider_early_reflections_keep_the_direct_path(gpu):
+    from sonicsim_amd import SonicSim_rir as RR
+    import torch
+    srcs = [[1.0, 1.5, 2.0], [1.5, 1.5, 2.2], [2.0, 1.5, 2.4]]
+    rcv = [0.0, 1.5, 0.0]
+    plain = torch.stack([RR.render_ir("roomX", s, rcv, channel_type="Mono", device=gpu) for s in srcs])          # (P, 1, L)
+    early = plain.clone()
+    RR.add_early_reflections(early, "roomX", srcs, rcv, np.ones((3, 1)), 16000, order=2)
+    diff = (early - plain).abs()
+    assert float(diff.max()) > 1e-3 and int((diff > 0).sum()) < 3 * 200                  # a sparse set of impulses
+    d = np.linalg.norm(np.array(srcs) - np.array(rcv), axis=1)
+    first = np.round(16000 * d / 343.0).astype(int)
+    for p in range(3):                                                                     # nothing arrives before the direct path
+        assert float(diff[p, 0, : first[p]].max()) == 0.0
