@@ -73,6 +73,16 @@ int ss_convolve_moving_f32(const float* x, int64_t T, const float* rirs, int32_t
  * irregular for the device planner's task buffer (where = row-tasks needed; nothing was rendered: use the default path). */
 int ss_async_status(int32_t* code, int64_t* where, void* stream);
 
+/* ---- how the render kernel's workgroups get their tasks (current device) --------------------------------------------------------
+ * 0 (default): static lists -- workgroup b of the persistent kernel renders tasks b, b + n, b + 2n, ... of the XCD-aware LPT plan.
+ * Fastest when the render has the GPU to itself, but a workgroup that cannot get onto the machine (another kernel -- RCCL's send /
+ * recv during the scene gather of a multi-GPU run, a copy kernel of another stream -- holds its compute unit) still owns its list:
+ * 4 of 256 compute units held = +60 % kernel time (tools/t_cu_steal.py, profiles/r02y).
+ * 1: dynamic queues -- one queue per XCD, every task (the first included) is taken with an atomic ticket; late workgroups find their
+ * queue drained.  1-3 % slower alone, degrades in proportion to the units held.  Use it whenever the render shares the GPU
+ * (bench.py does for N > 1 with the gather; sonicsim_amd.parallel.SceneGather users should). */
+int ss_set_task_queue(int dynamic);
+
 /* ---- rows I+V fused: SonicSim_moving.py:42-45 + :63-96 ---------------------------------------
  * Fast path of interpolate_moving_audio (SonicSim_moving.py:98-125).  The host keeps only the O(P)
  * half of setup_dynamic_interp (:32-39, the NumPy-RNG-coupled segment lengths n_k); the O(T)

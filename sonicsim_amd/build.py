@@ -20,6 +20,7 @@ OUT = os.path.join(PKG, "lib", "libsonicsim_hip.so")
 ASM_GEN = os.path.join(os.path.dirname(PKG), "tools", "gen_asm", "os13.py")
 ASM_SRC = os.path.join(PKG, "csrc", "k_os13_gfx950.s")          # generated, committed (reviewable)
 ASM_OUT = os.path.join(PKG, "lib", "k_os13_gfx950.hsaco")
+ASM_OUT_DYNQ = os.path.join(PKG, "lib", "k_os13_gfx950_dynq.hsaco")
 ARCH = "gfx950"
 
 
@@ -44,24 +45,34 @@ def llvm_bin(name: str) -> str:
     raise RuntimeError(f"{name} not found under /opt/rocm/lib/llvm/bin")
 
 
-def build_asm(force: bool = False, verbose: bool = False) -> str:
-    """Generate, assemble and link the hand-scheduled render kernel (gfx950 code object)."""
-    stale = force or not os.path.exists(ASM_OUT) or os.path.getmtime(ASM_GEN) > os.path.getmtime(ASM_OUT)
-    if not stale:
-        return ASM_OUT
-    os.makedirs(os.path.dirname(ASM_OUT), exist_ok=True)
-    with open(ASM_SRC + ".tmp", "w") as f:
-        subprocess.run([sys.executable, ASM_GEN], check=True, stdout=f)
-    os.replace(ASM_SRC + ".tmp", ASM_SRC)
-    obj = ASM_OUT + ".o"
-    cmds = [[llvm_bin("clang"), "-x", "assembler", "-target", "amdgcn-amd-amdhsa", f"-mcpu={ARCH}", "-c", ASM_SRC, "-o", obj],
-            [llvm_bin("ld.lld"), "-shared", obj, "-o", ASM_OUT + ".tmp"]]
+def _assemble(src: str, out: str, verbose: bool):
+    obj = out + ".o"
+    cmds = [[llvm_bin("clang"), "-x", "assembler", "-target", "amdgcn-amd-amdhsa", f"-mcpu={ARCH}", "-c", src, "-o", obj],
+            [llvm_bin("ld.lld"), "-shared", obj, "-o", out + ".tmp"]]
     for cmd in cmds:
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.run(cmd, check=True)
-    os.replace(ASM_OUT + ".tmp", ASM_OUT)
+    os.replace(out + ".tmp", out)
     os.remove(obj)
+
+
+def build_asm(force: bool = False, verbose: bool = False) -> str:
+    """Generate, assemble and link the hand-scheduled render kernel (gfx950 code objects): the product (static task lists,
+    ``csrc/k_os13_gfx950.s`` is its committed listing) and the dynamic-queue build (``OS13_OPT=dynq``, ss_set_task_queue)."""
+    def stale(out):
+        return force or not os.path.exists(out) or os.path.getmtime(ASM_GEN) > os.path.getmtime(out)
+    os.makedirs(os.path.dirname(ASM_OUT), exist_ok=True)
+    if stale(ASM_OUT):
+        with open(ASM_SRC + ".tmp", "w") as f:
+            subprocess.run([sys.executable, ASM_GEN], check=True, stdout=f, env={**os.environ, "OS13_OPT": ""})
+        os.replace(ASM_SRC + ".tmp", ASM_SRC)
+        _assemble(ASM_SRC, ASM_OUT, verbose)
+    if stale(ASM_OUT_DYNQ):
+        src = ASM_OUT_DYNQ[:-len(".hsaco")] + ".s"                  # (generated listing next to the code object, not committed)
+        with open(src, "w") as f:
+            subprocess.run([sys.executable, ASM_GEN], check=True, stdout=f, env={**os.environ, "OS13_OPT": "dynq"})
+        _assemble(src, ASM_OUT_DYNQ, verbose)
     return ASM_OUT
 
 

@@ -1298,6 +1298,9 @@ struct Ctx {
     hipModule_t mod13 = nullptr;          // hand-scheduled gfx950 render kernel (tools/gen_asm/os13.py -> lib/k_os13_gfx950.hsaco)
     hipFunction_t fn13 = nullptr;
     bool mod13_tried = false;
+    hipModule_t mod13q = nullptr;         // the same kernel with dynamic per-XCD task queues (OS13_OPT=dynq -> lib/k_os13_gfx950_dynq.hsaco)
+    hipFunction_t fn13q = nullptr;
+    bool mod13q_tried = false;
     int os_geom = 0;        // SS_OS_GEOM: 11 (B=2048, 256 thr) / 12 (B=4096, 512 thr, spectrum window); 0 = by filter length
     void* ws[WS_COUNT] = {};
     size_t ws_cap[WS_COUNT] = {};
@@ -1314,7 +1317,7 @@ struct Ctx {
     int os_ablate = 0;      // SS_OS_ABLATE: profiling-only ablation mask (results are WRONG when != 0)
     bool zero_copy = true;  // SS_ZERO_COPY_PLAN=0: upload the plan with a stream-ordered copy instead of device-mapped pinned memory
     bool xcd_order = true;  // SS_XCD_ORDER=0 disables the XCD-aware task order -- tuning knob
-    bool dynq = false;      // SS_DYNQ=1 (with a code object built with OS13_OPT=dynq): per-XCD dynamic task queues -- experiment, measured slower
+    bool dynq = false;      // ss_set_task_queue(1) / SS_DYNQ=1: per-XCD dynamic task queues (1-3 % slower alone, but robust when other kernels hold compute units)
     // host scratch reused across calls
     std::vector<int64_t> seg_start;
     std::vector<int32_t> bmin, bmax;
@@ -1473,19 +1476,23 @@ static_assert(sizeof(Os13AsmArgs) == 128, "Os13AsmArgs layout");
 
 // The code object sits next to this shared library (built by sonicsim_amd/build.py); a missing file is an error
 // for the callers that asked for the assembly engine, never a silent fallback.
-int load_mod13(Ctx* c) {
-    if (c->fn13) return SS_OK;
-    if (c->mod13_tried) return fail(SS_EHIP, "k_os13_gfx950.hsaco could not be loaded (see the first error)");
-    c->mod13_tried = true;
+int load_mod13(Ctx* c, bool dynq = false) {
+    hipModule_t& mod = dynq ? c->mod13q : c->mod13;
+    hipFunction_t& fn = dynq ? c->fn13q : c->fn13;
+    bool& tried = dynq ? c->mod13q_tried : c->mod13_tried;
+    const char* file = dynq ? "k_os13_gfx950_dynq.hsaco" : "k_os13_gfx950.hsaco";
+    if (fn) return SS_OK;
+    if (tried) return fail(SS_EHIP, "%s could not be loaded (see the first error)", file);
+    tried = true;
     Dl_info info;
-    if (!dladdr((const void*)&ss_version, &info) || !info.dli_fname) return fail(SS_EHIP, "dladdr failed: cannot locate k_os13_gfx950.hsaco");
+    if (!dladdr((const void*)&ss_version, &info) || !info.dli_fname) return fail(SS_EHIP, "dladdr failed: cannot locate %s", file);
     std::string path(info.dli_fname);
     const size_t slash = path.find_last_of('/');
-    path = (slash == std::string::npos ? std::string(".") : path.substr(0, slash)) + "/k_os13_gfx950.hsaco";
+    path = (slash == std::string::npos ? std::string(".") : path.substr(0, slash)) + "/" + file;
     if (const char* e = getenv("SS_HSACO")) path = e;
-    hipError_t e = hipModuleLoad(&c->mod13, path.c_str());
+    hipError_t e = hipModuleLoad(&mod, path.c_str());
     if (e != hipSuccess) return fail(SS_EHIP, "hipModuleLoad(%s) failed: %s", path.c_str(), hipGetErrorString(e));
-    e = hipModuleGetFunction(&c->fn13, c->mod13, "k_os13_asm");
+    e = hipModuleGetFunction(&fn, mod, "k_os13_asm");
     if (e != hipSuccess) return fail(SS_EHIP, "hipModuleGetFunction(k_os13_asm) failed: %s", hipGetErrorString(e));
     return SS_OK;
 }
@@ -1549,7 +1556,7 @@ int render(int mode, const float* x, int64_t T, const float* bank, int32_t P, in
                      (geom == 14 || (flags & SS_FLAG_GEOM_ASM) || (geom == 0 && L > 2 * B));   // hand-scheduled assembly engine (k_os13_asm):
                                                                                                 // the default for long filters
     const bool g12 = g13 || g14 || (use_os && T < ((int64_t)1 << 30) && geom == 12);     // 13/14 share 12's block size, spectra and plan
-    if (g14 && (rc = load_mod13(c))) return rc;
+    if (g14 && (rc = load_mod13(c, c->dynq))) return rc;
     if (xdiv && !(g13 || g14)) {       // engines without the fused scaling: divide a copy of x (linear in x)
         if ((rc = ws_ensure(c, WS_W, sizeof(float) * T))) return rc;
         hipLaunchKernelGGL(k_div_by, dim3(grid_for(T)), dim3(256), 0, stream, dx, (float*)c->ws[WS_W], T, xdiv);
@@ -1705,7 +1712,7 @@ int render(int mode, const float* x, int64_t T, const float* bank, int32_t P, in
                             // with the tasks the workgroups start on
                 const int nwg = (int)(n0 > (size_t)c->num_cu ? (size_t)c->num_cu : n0);
                 qgroups = !c->dynq ? 0 : ((nwg >= 8 && nwg % 8 == 0) ? 8 : 1);
-                qinit = qgroups ? nwg / qgroups : 0;
+                qinit = 0;                                   // every task, the first one included, comes from the queue
             }
             if (g13 || g14) hipLaunchKernelGGL(k_xspec13, dim3(M + 1), dim3(NT13), 0, stream, dx, T, (const c32*)c->consts13, (c32*)c->ws[WS_XS], M,
                                                dy, (int64_t)C * T, (g13 || qgroups) ? (int*)c->ws[WS_CNT] : (int*)nullptr, g13 ? 1 : qgroups,
@@ -1740,7 +1747,7 @@ int render(int mode, const float* x, int64_t T, const float* bank, int32_t P, in
             if (trace_file) a.counter = c->ws[WS_CNT];     // (zeroed ahead of the spectra kernel, which then sets the queue heads)
             size_t asz = sizeof(a);
             void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &asz, HIP_LAUNCH_PARAM_END};
-            HIPCHK(hipModuleLaunchKernel(c->fn13, (unsigned)nt, 1, 1, NT13, 1, 1, 0, stream, nullptr, cfg));
+            HIPCHK(hipModuleLaunchKernel(c->dynq ? c->fn13q : c->fn13, (unsigned)nt, 1, 1, NT13, 1, 1, 0, stream, nullptr, cfg));
             if (zero_copy_plan) {          // the ring slot may be rewritten only after this kernel has consumed it
                 HIPCHK(hipEventRecord(pin->ev, stream));
                 pin->pending = true;
@@ -1838,6 +1845,7 @@ int ss_shutdown(void) {
         if (c->consts13) hipFree(c->consts13);
         if (c->consts14) hipFree(c->consts14);
         if (c->mod13) hipModuleUnload(c->mod13);
+        if (c->mod13q) hipModuleUnload(c->mod13q);
         for (int i = 0; i < WS_COUNT; ++i) if (c->ws[i]) hipFree(c->ws[i]);
         if (c->async_status) hipFree(c->async_status);
         for (auto& p : c->ring) { if (p.host) hipHostFree(p.host); if (p.ev) hipEventDestroy(p.ev); }
@@ -1852,6 +1860,15 @@ int ss_shutdown(void) {
 int ss_convolve_moving_f32(const float* x, int64_t T, const float* rirs, int32_t P, int32_t C, int32_t L, const int64_t* idx,
                            const float* w, float* y, uint32_t flags, void* stream) {
     return render(COEF_EXPLICIT, x, T, rirs, P, C, L, nullptr, idx, w, y, flags, stream);
+}
+
+int ss_set_task_queue(int dynamic) {
+    Ctx* c;
+    int rc = get_ctx(&c);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lock(c->mu);
+    c->dynq = dynamic != 0;
+    return SS_OK;
 }
 
 int ss_async_status(int32_t* code, int64_t* where, void* stream_) {

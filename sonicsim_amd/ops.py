@@ -111,6 +111,13 @@ def convolve_moving(x, rirs, idx, w, path=None, out=None, validate=True):
     return y
 
 
+def set_task_queue(dynamic: bool):
+    """How the persistent render kernel's workgroups get their tasks on the current device: static lists (default, fastest when the
+    render has the GPU to itself) or dynamic per-XCD queues (robust when other kernels -- RCCL transfers, copies on other streams --
+    hold compute units: see include/sonicsim_hip.h)."""
+    _lib.check(_lib.load().ss_set_task_queue(1 if dynamic else 0))
+
+
 def async_status(stream_of=None):
     """stream_of: a device tensor whose device's current stream is synchronised (default: the current device's current stream).
     (code, where) latched by renders issued with validate=False on the current device, then cleared: 0 = none,

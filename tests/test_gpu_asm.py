@@ -144,3 +144,31 @@ def test_random_shape_sweep(gpu):
         y = ops.convolve_moving_seg(x, bank, seg)
         assert_parity(y, ref)
         assert np.array_equal(ops.convolve_moving(x, bank, idx, w), y), (case, T, P, C, L)
+
+
+def test_dynamic_task_queues_same_bits(gpu):
+    """ss_set_task_queue(1): the render kernel's workgroups take every task from per-XCD queues (robust when other kernels hold compute
+    units); every output sample still receives its two addends, so all schedules give the bits of the static lists."""
+    import torch
+    from oracle import moving as O
+    from sonicsim_amd import ops, synth
+    try:
+        for kw in (dict(L=9000), dict(T=200000, P=30, C=2, L=48000), dict(T=70001, P=12, C=2, L=20000)):
+            sc = synth.make_scene("tiny", scene=1, **kw)
+            seg = synth.scene_segments(sc, 1)
+            bank = torch.from_numpy(np.random.default_rng(5).standard_normal((sc.P, sc.C, sc.L)).astype(np.float32) * 0.05).to(gpu)
+            x = torch.from_numpy(sc.x).to(gpu)
+            idx, w = O.expand_segments(seg)
+            di, dw = torch.from_numpy(idx).to(gpu), torch.from_numpy(w).to(gpu)
+            ops.set_task_queue(False)
+            want = [ops.convolve_moving_seg(x, bank, seg, path="asm"), ops.convolve_moving(x, bank, di, dw, path="asm"),
+                    ops.convolve_fixed(x, bank[0], path="asm")]
+            ops.set_task_queue(True)
+            got = [ops.convolve_moving_seg(x, bank, seg, path="asm"), ops.convolve_moving(x, bank, di, dw, path="asm"),
+                   ops.convolve_fixed(x, bank[0], path="asm"), ops.convolve_moving(x, bank, di, dw, path="asm", validate=False)]
+            assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1]) and torch.equal(got[2], want[2]) and torch.equal(got[3], want[1])
+            assert ops.async_status() == (0, 0)
+            ref = O.convolve_moving_receiver(sc.x, bank.cpu().numpy(), idx, w)
+            assert O.rel_rms(got[0].cpu().numpy(), ref) <= 1e-4
+    finally:
+        ops.set_task_queue(False)
