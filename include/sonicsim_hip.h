@@ -79,7 +79,8 @@ int ss_async_status(int32_t* code, int64_t* where, void* stream);
  * recv during the scene gather of a multi-GPU run, a copy kernel of another stream -- holds its compute unit) still owns its list:
  * 4 of 256 compute units held = +60 % kernel time (tools/t_cu_steal.py, profiles/r02y).
  * 1: dynamic queues -- one queue per XCD, every task (the first included) is taken with an atomic ticket; late workgroups find their
- * queue drained.  1-3 % slower alone, degrades in proportion to the units held.  Use it whenever the render shares the GPU
+ * queue drained.  As fast as the static lists alone (within noise, more run-to-run spread), degrades in proportion to the units held.
+ * Use it whenever the render shares the GPU
  * (bench.py does for N > 1 with the gather; sonicsim_amd.parallel.SceneGather users should). */
 int ss_set_task_queue(int dynamic);
 
