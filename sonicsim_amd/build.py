@@ -94,5 +94,22 @@ def build(force: bool = False, verbose: bool = False, extra=None, out=None) -> s
     return out or OUT
 
 
+TUNING_OUT = os.path.join(PKG, "lib", "libsonicsim_hip_tuning.so")
+
+
+def build_tuning(force: bool = False, verbose: bool = False) -> str:
+    """The library the tools/ scripts use: the product source with -DSS_TUNING_KNOBS, i.e. with the environment switches of the
+    experiments (SS_HSACO, SS_TRACE_FILE, SS_DYNQ, SS_OS_GEOM, SS_HOP_RS, ...).  The product library reads no environment variable
+    (one test switch aside).  Select it with SS_LIB=<this path>."""
+    build_asm(force=force, verbose=verbose)
+    srcs = [SRC] + [os.path.join(os.path.dirname(SRC), f) for f in os.listdir(os.path.dirname(SRC)) if f.endswith(".h")]
+    if not force and os.path.exists(TUNING_OUT) and all(os.path.getmtime(f) <= os.path.getmtime(TUNING_OUT) for f in srcs):
+        return TUNING_OUT
+    return build(force=True, verbose=verbose, extra=["-DSS_TUNING_KNOBS"], out=TUNING_OUT)
+
+
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    if "--tuning" in sys.argv:
+        print(build_tuning(force="--force" in sys.argv, verbose=True))
+    else:
+        print(build(force="--force" in sys.argv, verbose=True))

@@ -17,6 +17,15 @@
 #include "plan.h"
 #include "tvfir_core.h"
 
+// Tuning / experiment switches (SS_OS_GEOM, SS_HSACO, SS_TRACE_FILE, SS_HOP_RS, ...) exist only in the library the tools build with
+// -DSS_TUNING_KNOBS (sonicsim_amd/build.py::build_tuning, lib/libsonicsim_hip_tuning.so); the product library reads no environment variable.
+#ifdef SS_TUNING_KNOBS
+static inline const char* knob(const char* name) { return getenv(name); }
+#else
+static inline const char* knob(const char*) { return nullptr; }
+#endif
+
+
 using namespace ss;
 
 // =============================================================================================
@@ -1369,14 +1378,14 @@ int get_ctx(Ctx** out) {
         hipDeviceProp_t prop;
         HIPCHK(hipGetDeviceProperties(&prop, dev));
         c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-        if (const char* e = getenv("SS_OS_GEOM")) c->os_geom = atoi(e);
-        if (const char* e = getenv("SS_OS_VARIANT")) c->os_variant = atoi(e);
+        if (const char* e = knob("SS_OS_GEOM")) c->os_geom = atoi(e);
+        if (const char* e = knob("SS_OS_VARIANT")) c->os_variant = atoi(e);
 #ifdef SS_ABLATE
-        if (const char* e = getenv("SS_OS_ABLATE")) c->os_ablate = atoi(e);
+        if (const char* e = knob("SS_OS_ABLATE")) c->os_ablate = atoi(e);
 #endif
-        if (const char* e = getenv("SS_XCD_ORDER")) c->xcd_order = atoi(e) != 0;
-        if (const char* e = getenv("SS_ZERO_COPY_PLAN")) c->zero_copy = atoi(e) != 0;
-        if (const char* e = getenv("SS_DYNQ")) c->dynq = atoi(e) != 0;
+        if (const char* e = knob("SS_XCD_ORDER")) c->xcd_order = atoi(e) != 0;
+        if (const char* e = knob("SS_ZERO_COPY_PLAN")) c->zero_copy = atoi(e) != 0;
+        if (const char* e = knob("SS_DYNQ")) c->dynq = atoi(e) != 0;
         c->inited = true;
     }
     *out = c;
@@ -1489,7 +1498,7 @@ int load_mod13(Ctx* c, bool dynq = false) {
     std::string path(info.dli_fname);
     const size_t slash = path.find_last_of('/');
     path = (slash == std::string::npos ? std::string(".") : path.substr(0, slash)) + "/" + file;
-    if (const char* e = getenv("SS_HSACO")) path = e;
+    if (const char* e = knob("SS_HSACO")) path = e;
     hipError_t e = hipModuleLoad(&mod, path.c_str());
     if (e != hipSuccess) return fail(SS_EHIP, "hipModuleLoad(%s) failed: %s", path.c_str(), hipGetErrorString(e));
     e = hipModuleGetFunction(&fn, mod, "k_os13_asm");
@@ -1570,7 +1579,7 @@ int render(int mode, const float* x, int64_t T, const float* bank, int32_t P, in
     // row's first block starts within one hop of its first sample (plan.h row_tasks) -- 8 % fewer blocks and 6 % fewer tasks at config 2,
     // but the kernel gains only 1.5 % (twice the spectra in L2), the spectra kernel loses as much, and the implicit schedule is no longer
     // bit-identical to the explicit one (different block decomposition): profiles/r02r.
-    static const int hop_rs_env = getenv("SS_HOP_RS") ? atoi(getenv("SS_HOP_RS")) : 0;
+    static const int hop_rs_env = knob("SS_HOP_RS") ? atoi(knob("SS_HOP_RS")) : 0;
     const int rs = g14 ? (hop_rs_env < 0 ? 0 : (hop_rs_env > 2 ? 2 : hop_rs_env)) : 0;
     const int M = g14 ? (int)((T + (BB >> rs) - 1) / (BB >> rs)) + (1 << rs) - 1 : (int)((T + BB - 1) / BB);   // number of input spectra
     const int NPart = (L + BB - 1) / BB;
@@ -1639,8 +1648,8 @@ int render(int mode, const float* x, int64_t T, const float* bank, int32_t P, in
     if (dev_plan) {
     } else if (fast_plan) {
         // XCD-aware task order for the persistent assembly kernel (workgroup b -> XCD b % 8 takes tasks b, b + nwg, ...)
-        static const int plan_groups = getenv("SS_PLAN_GROUPS") ? atoi(getenv("SS_PLAN_GROUPS")) : 8;
-        static const int plan_snake = getenv("SS_PLAN_SNAKE") ? atoi(getenv("SS_PLAN_SNAKE")) : 1;
+        static const int plan_groups = knob("SS_PLAN_GROUPS") ? atoi(knob("SS_PLAN_GROUPS")) : 8;
+        static const int plan_snake = knob("SS_PLAN_SNAKE") ? atoi(knob("SS_PLAN_SNAKE")) : 1;
         plan_seg_lpt(c->seg_start, P, C, BB, JM, NPart, c->plan.tasks[0], c->plan_scratch, (g14 && plan_groups > 1 && plan_groups <= 64) ? plan_groups : 1,
                      plan_snake ? c->num_cu : 0, rs);
         c->plan.tasks[1].clear();
@@ -1693,7 +1702,7 @@ int render(int mode, const float* x, int64_t T, const float* bank, int32_t P, in
     }
 
     int qgroups = 0, qinit = 0;
-    const char* trace_env = getenv("SS_TRACE_FILE");      // timeline trace of a code object built with OS13_OPT=trace (tools/)
+    const char* trace_env = knob("SS_TRACE_FILE");      // timeline trace of a code object built with OS13_OPT=trace (tools/)
     RenderParams prm;
     memset(&prm, 0, sizeof(prm));
     prm.x = dx; prm.T = T; prm.bank = dbank; prm.P = P; prm.C = C; prm.L = L; prm.NP = NPart;
@@ -1956,7 +1965,7 @@ static int rir_synth(const SsRirParams* p, float* bank, float* peak, uint32_t fl
     // taps per thread: the chain over the positions is sequential, so the parallelism is C * L / V threads.  Four taps per thread
     // (16-byte stores) leave a config-2 bank (384 000 taps per position) with 1 500 waves for 1 024 SIMDs -- half of them carry two
     // waves, the others one; two taps per thread (3 000 waves) fill them evenly: 129 -> ~100 us.  V = 4 from 4 waves per SIMD on.
-    static const int synth_v = getenv("SS_SYNTH_V") ? atoi(getenv("SS_SYNTH_V")) : 0;
+    static const int synth_v = knob("SS_SYNTH_V") ? atoi(knob("SS_SYNTH_V")) : 0;
     const bool big = CL / 4 / 64 >= (int64_t)c->num_cu * 16;
     const bool vec4 = p->L % 4 == 0 && ((uintptr_t)dbank & 15) == 0 && (synth_v ? synth_v == 4 : big);
     const bool vec2 = !vec4 && p->L % 2 == 0 && ((uintptr_t)dbank & 7) == 0 && (synth_v ? synth_v == 2 : true);
@@ -2259,7 +2268,7 @@ static int kw_block_power_dev(Ctx* c, const float* da, int64_t T, int32_t C, int
         for (int i = 0; i < 16; ++i) mx = std::max(mx, std::fabs(k.Mp[hp][i]));
         if (mx <= 1e-20) break;
     }
-    const char* fe = getenv("SS_KW_EXACT");          // tests: force the exact multi-launch scan
+    const char* fe = getenv("SS_KW_EXACT");        // test switch (the only environment variable the product library reads): force the exact multi-launch scan
     const bool force_exact = fe && atoi(fe);
     if (hp <= 8 && !force_exact) {
         const int H = 1 << hp;

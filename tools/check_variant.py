@@ -3,7 +3,9 @@
     SS_HSACO=$PWD/tools/var/<name>.hsaco [SS_DYNQ=0] python tools/check_variant.py <label> [--cfg5]
 Prints one line: parity of the implicit / explicit / fixed schedules against the HIP geometry-12 engine and the oracle on small
 shapes, then the sustained kernel time at config 2 (HIP events around every launch, 200 launches after an 80 ms pre-roll)."""
+import os
 import sys
+os.environ.setdefault("SS_LIB", os.path.abspath("sonicsim_amd/lib/libsonicsim_hip_tuning.so"))   # experiment switches: tuning build
 import time
 
 import numpy as np

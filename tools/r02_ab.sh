@@ -1,6 +1,7 @@
 #!/bin/bash
 # A/B of several assembly-kernel variants against the product kernel: N interleaved rounds (tools/check_variant.py, fresh processes)
 # usage: tools/r02_ab.sh <tag> <rounds> <variant> [<variant> ...]
+
 TAG=$1; ROUNDS=$2; shift 2
 OUT=gpurun_out/$TAG; mkdir -p $OUT
 V=$PWD/tools/var

@@ -1,5 +1,6 @@
 #!/bin/bash
 # A/B of the input-spectra grid (SS_HOP_RS = 0: block grid, 1: 2048, 2: 1024) with the product code object: parity + timing, cfg2 and cfg5
+
 TAG=$1; ROUNDS=${2:-2}
 OUT=gpurun_out/$TAG; mkdir -p $OUT
 for r in $(seq $ROUNDS); do

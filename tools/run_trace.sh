@@ -1,5 +1,7 @@
 #!/bin/bash
 # GPU box: per-phase timeline of waves 0 and 4 (one SIMD) of workgroup 0 for one config-2 render (code object built with OS13_OPT=trace)
+export SS_LIB=$PWD/sonicsim_amd/lib/libsonicsim_hip_tuning.so      # the experiment switches live in the tuning build (python -m sonicsim_amd.build --tuning)
+
 mkdir -p gpurun_out
 SS_HSACO=$PWD/tools/var/trace.hsaco SS_TRACE_FILE=gpurun_out/trace.bin timeout 120 python - <<'PY'
 import sys, torch

@@ -1,4 +1,5 @@
 import sys, time, os
+os.environ.setdefault("SS_LIB", os.path.abspath("sonicsim_amd/lib/libsonicsim_hip_tuning.so"))   # SS_SYNTH_V lives in the tuning build
 sys.path.insert(0, ".")
 import torch, numpy as np
 from sonicsim_amd import ops, synth

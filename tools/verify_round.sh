@@ -1,6 +1,7 @@
 #!/bin/bash
 # GPU box, one call: the whole -m gpu suite, an A/B of the render kernel against the schedule without wave priorities, the three bench lines,
 # kernel trace + PMC passes (tools/profile.sh), smoke() and the secondary timings -> gpurun_out/<tag>/, gpurun_out/prof_<tag>/
+
 TAG=${1:-round}
 OUT=gpurun_out/$TAG; mkdir -p $OUT
 export TMPDIR=/tmp
