@@ -146,8 +146,7 @@ def run_cfg2(args, rank, local_rank, world, dev):
     torch.cuda.synchronize()
     ge = max(1, args.gather_every)
     do_gather = world > 1 and not args.no_gather
-    if do_gather:
-        ops.set_task_queue(True)           # RCCL's send / recv kernels hold compute units while a scene travels: dynamic task queues (ss_set_task_queue)
+    ops.set_task_queue(os.environ.get("BENCH_STATIC_LISTS") != "1")      # dynamic task queues (the default): RCCL's send / recv kernels hold compute units while a scene travels
     ngath = args.steps // ge if do_gather else 0
 
     def make_gather():
@@ -246,7 +245,7 @@ def run_cfg2(args, rank, local_rank, world, dev):
         "config": {"workload": f"{args.config}: single moving source, {sc.C}-mic, {audio_s:.0f} s @ {sc.fs} Hz, "
                                f"{sc.P} trajectory points, {sc.L}-tap RIRs (T={sc.T})",
                    "T": sc.T, "P": sc.P, "C": sc.C, "L": sc.L, "fs": sc.fs,
-                   "entry_point": "ss_convolve_moving_seg_f32", "parallelism": f"scene-sharded x{world}", "task_queue": "dynamic (per XCD)" if do_gather else "static lists",
+                   "entry_point": "ss_convolve_moving_seg_f32", "parallelism": f"scene-sharded x{world}", "task_queue": "dynamic, one per XCD (the default; ss_set_task_queue)",
                    "gather": f"every {ge}th render of every rank to rank 0, overlapped with the next renders" if do_gather else False,
                    "value_is": "sustained: K timed steps after an untimed pre-roll + W warm-up steps; value_cold = K steps right after the "
                                "W warm-up steps of the fresh process",
@@ -290,9 +289,6 @@ def run_scenes(args, rank, local_rank, world, dev):
     pool = [pipeline.make_scene_spec(dev, scene=rank * 4 + i, config="cfg2") for i in range(min(4, per_rank))]   # dry signals + geometry cycle
     rend = pipeline.SceneRenderer(pool[0], dev)
     gather = args.config == "cfg4" and not args.no_gather
-    if gather and world > 1:
-        from sonicsim_amd import ops
-        ops.set_task_queue(True)           # the render shares the GPU with RCCL's transfer kernels (ss_set_task_queue)
     np.random.seed(7000 + rank)
     torch.manual_seed(7000 + rank)
     import gc

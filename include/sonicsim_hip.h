@@ -74,14 +74,13 @@ int ss_convolve_moving_f32(const float* x, int64_t T, const float* rirs, int32_t
 int ss_async_status(int32_t* code, int64_t* where, void* stream);
 
 /* ---- how the render kernel's workgroups get their tasks (current device) --------------------------------------------------------
- * 0 (default): static lists -- workgroup b of the persistent kernel renders tasks b, b + n, b + 2n, ... of the XCD-aware LPT plan.
- * Fastest when the render has the GPU to itself, but a workgroup that cannot get onto the machine (another kernel -- RCCL's send /
- * recv during the scene gather of a multi-GPU run, a copy kernel of another stream -- holds its compute unit) still owns its list:
- * 4 of 256 compute units held = +60 % kernel time (tools/t_cu_steal.py, profiles/r02y).
- * 1: dynamic queues -- one queue per XCD, every task (the first included) is taken with an atomic ticket; late workgroups find their
- * queue drained.  As fast as the static lists alone (within noise, more run-to-run spread), degrades in proportion to the units held.
- * Use it whenever the render shares the GPU
- * (bench.py does for N > 1 with the gather; sonicsim_amd.parallel.SceneGather users should). */
+ * 1 (default): dynamic queues -- one queue per XCD holding that XCD's stretch of the LPT plan; every task (the first included) is taken
+ * with an atomic ticket, one task ahead so that its round trip is never waited for.  A workgroup that gets onto the machine late --
+ * another kernel (RCCL's send / recv during the scene gather of a multi-GPU run, a copy kernel of another stream, anything) holds its
+ * compute unit -- finds its queue drained; the render degrades in proportion to the units held (tools/t_cu_steal.py, profiles/r02y).
+ * 0: static lists -- workgroup b renders tasks b, b + n, b + 2n, ...  Equally fast on a GPU the render has entirely to itself and
+ * with less run-to-run spread, but a workgroup that cannot be placed still owns its list: 4 of 256 compute units held = +62 % kernel
+ * time.  Same output bits either way. */
 int ss_set_task_queue(int dynamic);
 
 /* ---- rows I+V fused: SonicSim_moving.py:42-45 + :63-96 ---------------------------------------

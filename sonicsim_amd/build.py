@@ -58,8 +58,8 @@ def _assemble(src: str, out: str, verbose: bool):
 
 
 def build_asm(force: bool = False, verbose: bool = False) -> str:
-    """Generate, assemble and link the hand-scheduled render kernel (gfx950 code objects): the product (static task lists,
-    ``csrc/k_os13_gfx950.s`` is its committed listing) and the dynamic-queue build (``OS13_OPT=dynq``, ss_set_task_queue)."""
+    """Generate, assemble and link the hand-scheduled render kernel (gfx950 code objects): the dynamic-queue build (``OS13_OPT=dynq``,
+    the default: ``csrc/k_os13_gfx950_dynq.s``) and the static-list build (``csrc/k_os13_gfx950.s``; ``ss_set_task_queue(0)``)."""
     def stale(out):
         return force or not os.path.exists(out) or os.path.getmtime(ASM_GEN) > os.path.getmtime(out)
     os.makedirs(os.path.dirname(ASM_OUT), exist_ok=True)
@@ -69,9 +69,10 @@ def build_asm(force: bool = False, verbose: bool = False) -> str:
         os.replace(ASM_SRC + ".tmp", ASM_SRC)
         _assemble(ASM_SRC, ASM_OUT, verbose)
     if stale(ASM_OUT_DYNQ):
-        src = ASM_OUT_DYNQ[:-len(".hsaco")] + ".s"                  # (generated listing next to the code object, not committed)
-        with open(src, "w") as f:
+        src = ASM_SRC[:-len(".s")] + "_dynq.s"                       # csrc/k_os13_gfx950_dynq.s: the committed listing of the default kernel
+        with open(src + ".tmp", "w") as f:
             subprocess.run([sys.executable, ASM_GEN], check=True, stdout=f, env={**os.environ, "OS13_OPT": "dynq"})
+        os.replace(src + ".tmp", src)
         _assemble(src, ASM_OUT_DYNQ, verbose)
     return ASM_OUT
 

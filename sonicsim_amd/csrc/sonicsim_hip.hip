@@ -1326,7 +1326,7 @@ struct Ctx {
     int os_ablate = 0;      // SS_OS_ABLATE: profiling-only ablation mask (results are WRONG when != 0)
     bool zero_copy = true;  // SS_ZERO_COPY_PLAN=0: upload the plan with a stream-ordered copy instead of device-mapped pinned memory
     bool xcd_order = true;  // SS_XCD_ORDER=0 disables the XCD-aware task order -- tuning knob
-    bool dynq = false;      // ss_set_task_queue(1) / SS_DYNQ=1: per-XCD dynamic task queues (robust when other kernels hold compute units; alone as fast as the static lists, with more spread)
+    bool dynq = true;       // default; ss_set_task_queue(0) selects the static lists: per-XCD dynamic task queues (robust when anything else holds compute units; alone as fast as the static lists)
     // host scratch reused across calls
     std::vector<int64_t> seg_start;
     std::vector<int32_t> bmin, bmax;

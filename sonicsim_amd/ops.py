@@ -112,9 +112,9 @@ def convolve_moving(x, rirs, idx, w, path=None, out=None, validate=True):
 
 
 def set_task_queue(dynamic: bool):
-    """How the persistent render kernel's workgroups get their tasks on the current device: static lists (default, fastest when the
-    render has the GPU to itself) or dynamic per-XCD queues (robust when other kernels -- RCCL transfers, copies on other streams --
-    hold compute units: see include/sonicsim_hip.h)."""
+    """How the persistent render kernel's workgroups get their tasks on the current device: dynamic per-XCD queues (default: robust
+    when other kernels -- RCCL transfers, copies on other streams -- hold compute units) or static lists (same speed on a GPU the
+    render has entirely to itself, less timing spread, +62 % kernel time with 4 of 256 units held: see include/sonicsim_hip.h)."""
     _lib.check(_lib.load().ss_set_task_queue(1 if dynamic else 0))
 
 

@@ -78,9 +78,9 @@ class SceneGather:
       the render stream wait for the transfer that last used it.
     * ``submit(j)`` enqueues step j's transfers (grouped point-to-point: the root's xGMI links receive in parallel) on a side
       stream that waits for the render stream, so the render of step j+1 starts immediately.
-    * while a transfer is in flight RCCL's send / recv kernels hold compute units: select the render kernel's dynamic task queues
-      (``ops.set_task_queue(True)``) in a process that uses this class on GPUs -- the default static lists lose 60 % when 4 of the 256
-      units are taken (profiles/r02y).
+    * while a transfer is in flight RCCL's send / recv kernels hold compute units: keep the render kernel's default dynamic task queues
+      (``ops.set_task_queue``) in a process that uses this class on GPUs -- the static lists lose 60 % when 4 of the 256 units are taken
+      (profiles/r02y).
     Every rank calls ``slot(j)`` / ``submit(j)`` for j = 0 .. steps()-1 in order (ranks with fewer scenes just take part in the
     bookkeeping).  With the gloo backend / CPU tensors (tests) the transfers are synchronous and the order is the same."""
 

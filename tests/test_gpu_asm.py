@@ -147,8 +147,8 @@ def test_random_shape_sweep(gpu):
 
 
 def test_dynamic_task_queues_same_bits(gpu):
-    """ss_set_task_queue(1): the render kernel's workgroups take every task from per-XCD queues (robust when other kernels hold compute
-    units); every output sample still receives its two addends, so all schedules give the bits of the static lists."""
+    """ss_set_task_queue: the render kernel's workgroups take every task from per-XCD queues (default: robust when other kernels hold
+    compute units) or from static lists; every output sample receives its two addends either way, so the bits are the same."""
     import torch
     from oracle import moving as O
     from sonicsim_amd import ops, synth
@@ -171,4 +171,4 @@ def test_dynamic_task_queues_same_bits(gpu):
             ref = O.convolve_moving_receiver(sc.x, bank.cpu().numpy(), idx, w)
             assert O.rel_rms(got[0].cpu().numpy(), ref) <= 1e-4
     finally:
-        ops.set_task_queue(False)
+        ops.set_task_queue(True)                       # (the default)

@@ -3,7 +3,7 @@
 export SS_LIB=$PWD/sonicsim_amd/lib/libsonicsim_hip_tuning.so      # the experiment switches live in the tuning build (python -m sonicsim_amd.build --tuning)
 
 mkdir -p gpurun_out
-SS_HSACO=$PWD/tools/var/trace.hsaco SS_TRACE_FILE=gpurun_out/trace.bin timeout 120 python - <<'PY'
+SS_DYNQ=0 SS_HSACO=$PWD/tools/var/trace.hsaco SS_TRACE_FILE=gpurun_out/trace.bin timeout 120 python - <<'PY'
 import sys, torch
 sys.path.insert(0, ".")
 from sonicsim_amd import ops, synth

@@ -7,7 +7,7 @@ OUT=gpurun_out/$TAG; mkdir -p $OUT
 export TMPDIR=/tmp
 V=$PWD/tools/var
 echo "== pytest -m gpu"; timeout 900 python -m pytest tests -m gpu -q 2>&1 | tail -5 | tee $OUT/pytest.log
-echo "== A/B with cfg5"; for r in 1 2; do timeout 90 env SS_HSACO=$V/base.hsaco python tools/check_variant.py base-noprio --cfg5; timeout 90 python tools/check_variant.py product --cfg5; timeout 90 env SS_DYNQ=1 python tools/check_variant.py dynamic-queues --cfg5; done 2>&1 | grep "^\[" | sed 's/small-shape.*deterministic [A-Za-z]* | //' | tee $OUT/variants.log
+echo "== A/B with cfg5"; for r in 1 2; do timeout 90 env SS_DYNQ=0 SS_HSACO=$V/base.hsaco python tools/check_variant.py static-noprio --cfg5; timeout 90 env SS_DYNQ=0 python tools/check_variant.py static-lists --cfg5; timeout 90 python tools/check_variant.py product --cfg5; done 2>&1 | grep "^\[" | sed 's/small-shape.*deterministic [A-Za-z]* | //' | tee $OUT/variants.log
 echo "== bench"; timeout 300 python bench.py --steps 20 --warmup 5 2>$OUT/bench.err | tee $OUT/bench.json | cut -c1-300
 timeout 200 python bench.py --config cfg5 --steps 10 --warmup 2 --cpu-seconds 0 2>$OUT/bench_cfg5.err | tee $OUT/bench_cfg5.json | cut -c1-300
 timeout 200 python bench.py --config cfg4 --steps 64 --warmup 2 2>$OUT/bench_cfg4.err | tee $OUT/bench_cfg4.json | cut -c1-300
