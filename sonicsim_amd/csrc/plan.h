@@ -193,7 +193,8 @@ template <class F> inline void row_tasks(int64_t a0, int64_t a2, int block, int 
 }
 
 inline void plan_seg_lpt(const std::vector<int64_t>& seg_start /*[P], last == T*/, int P, int C, int block, int jmax, int NP,
-                         std::vector<Task>& out, std::vector<int32_t>& scratch, int groups = 1, int nwg = 0, int rs = 0) {
+                         std::vector<Task>& out, std::vector<int32_t>& scratch, int groups = 1, int nwg = 0, int rs = 0, int tail_pct = 0,
+                         int32_t* main_out = nullptr) {
     out.clear();
     constexpr int MAXCOST = 4096;
     auto cost = [NP, rs](int j0, int nj) {
@@ -253,6 +254,28 @@ inline void plan_seg_lpt(const std::vector<int64_t>& seg_start /*[P], last == T*
         int32_t next[64], end[64];
         int32_t off = 0;
         for (int g = 0; g < groups; ++g) { next[g] = off; off += gcount[g]; end[g] = off; }
+        if (main_out) *main_out = total;
+        if (tail_pct > 0 && tail_pct < 100) {
+            // dynamic queues with a shared tail (ss_set_task_queue(1)): the first m tasks of every range stay in that range's queue
+            // (list positions g, g + groups, ...: XCD g's queue), the smallest tail_pct % of the shortest range -- and whatever the
+            // longer ranges have beyond m -- form ONE queue behind them, in descending cost, which every workgroup turns to when its
+            // own queue is drained: the ranges' different speeds and the task granularity are evened out across the XCDs.
+            int32_t m = INT32_MAX;
+            for (int g = 0; g < groups; ++g) m = std::min(m, gcount[g]);
+            m = (int32_t)((int64_t)m * (100 - tail_pct) / 100);
+            out.resize((size_t)total);
+            int32_t off = 0, start[64];
+            for (int g = 0; g < groups; ++g) { start[g] = off; off += gcount[g]; }
+            for (int32_t k = 0; k < m; ++k)
+                for (int g = 0; g < groups; ++g) out[(size_t)k * groups + g] = tmp[(size_t)start[g] + k];
+            size_t w = (size_t)m * groups;
+            for (int g = 0; g < groups; ++g)
+                for (int32_t k = m; k < gcount[g]; ++k) out[w++] = tmp[(size_t)start[g] + k];
+            std::stable_sort(out.begin() + (size_t)m * groups, out.end(),
+                             [&](const Task& a, const Task& b) { return cost(a.j0, a.nj) > cost(b.j0, b.nj); });
+            if (main_out) *main_out = m * groups;
+            return;
+        }
         // the nwg / groups workgroups of a range take its list round-robin; dealing every second round in the opposite direction
         // (boustrophedon) keeps the first workgroup from collecting the largest task of every round
         const int bins = nwg > 0 && nwg % groups == 0 ? nwg / groups : 0;

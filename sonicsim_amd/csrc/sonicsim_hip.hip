@@ -1645,13 +1645,16 @@ int render(int mode, const float* x, int64_t T, const float* bank, int32_t P, in
                             (long long)(b * DTILE), c->bmin[b], c->bmax[b]);
     }
     const bool fast_plan = g12 && mode == COEF_SEG;        // single-launch geometries, implicit schedule: O(P*C) direct planner
+    int32_t qmain = 0;                                     // dynamic queues: tasks in the per-XCD part of the list (0 = all)
     if (dev_plan) {
     } else if (fast_plan) {
         // XCD-aware task order for the persistent assembly kernel (workgroup b -> XCD b % 8 takes tasks b, b + nwg, ...)
         static const int plan_groups = knob("SS_PLAN_GROUPS") ? atoi(knob("SS_PLAN_GROUPS")) : 8;
         static const int plan_snake = knob("SS_PLAN_SNAKE") ? atoi(knob("SS_PLAN_SNAKE")) : 1;
+        static const int plan_tail = knob("SS_PLAN_TAIL") ? atoi(knob("SS_PLAN_TAIL")) : 12;      // % of a range's tasks that go to the shared tail queue
+        const bool two_level = g14 && c->dynq && plan_groups == 8;
         plan_seg_lpt(c->seg_start, P, C, BB, JM, NPart, c->plan.tasks[0], c->plan_scratch, (g14 && plan_groups > 1 && plan_groups <= 64) ? plan_groups : 1,
-                     plan_snake ? c->num_cu : 0, rs);
+                     (plan_snake && !two_level) ? c->num_cu : 0, rs, two_level ? plan_tail : 0, &qmain);
         c->plan.tasks[1].clear();
     } else {
         if (mode == COEF_SEG) seg_minmax(c->seg_start, T, c->bmin, c->bmax);
@@ -1715,7 +1718,7 @@ int render(int mode, const float* x, int64_t T, const float* bank, int32_t P, in
         prm.Xs = (const c32*)c->ws[WS_XS];
         {
             ProfScope ps(c, stream, 1);
-            if ((g13 || g14) && (rc = ws_ensure(c, WS_CNT, trace_env ? 512 * 1024 : 8 * 64))) return rc;
+            if ((g13 || g14) && (rc = ws_ensure(c, WS_CNT, trace_env ? 512 * 1024 : 16 * 64))) return rc;     // queue heads: 8 XCD queues + the shared tail queue, 64 bytes apart
             if (g14 && trace_env) HIPCHK(hipMemsetAsync(c->ws[WS_CNT], 0, 512 * 1024, stream));   // stamps / trace records land behind the queue heads
             if (g14) {      // dynamic task queues of the assembly kernel: one head per XCD (workgroup b runs on XCD b % 8), preloaded
                             // with the tasks the workgroups start on
@@ -1724,7 +1727,7 @@ int render(int mode, const float* x, int64_t T, const float* bank, int32_t P, in
                 qinit = 0;                                   // every task, the first one included, comes from the queue
             }
             if (g13 || g14) hipLaunchKernelGGL(k_xspec13, dim3(M + 1), dim3(NT13), 0, stream, dx, T, (const c32*)c->consts13, (c32*)c->ws[WS_XS], M,
-                                               dy, (int64_t)C * T, (g13 || qgroups) ? (int*)c->ws[WS_CNT] : (int*)nullptr, g13 ? 1 : qgroups,
+                                               dy, (int64_t)C * T, (g13 || qgroups) ? (int*)c->ws[WS_CNT] : (int*)nullptr, g13 ? 1 : qgroups + 1,
                                                g13 ? 0 : qinit, xdiv, rs);
             else if (g12) hipLaunchKernelGGL(k_xspec12, dim3(M + 1), dim3(NT12), 0, stream, dx, T, (const c32*)c->consts12, (c32*)c->ws[WS_XS], M,
                                         dy, (int64_t)C * T, (int*)nullptr);
@@ -1751,7 +1754,8 @@ int render(int mode, const float* x, int64_t T, const float* bank, int32_t P, in
             a.ntasks = prm.ntasks; a.mode = mode; a.nwg = (int32_t)nt;
             a.consts = c->consts14; a.counter = qgroups ? c->ws[WS_CNT] : nullptr;
             a.idx = didx; a.w = dw;
-            a.qgroups = qgroups; a.rs = rs;
+            a.qgroups = qgroups;
+            a.rs = rs | ((qgroups == 8 && qmain > 0 && qmain < (1 << 22) && (size_t)qmain < n0) ? qmain << 8 : 0);   // bits 8..: the queue split
             const char* trace_file = trace_env;
             if (trace_file) a.counter = c->ws[WS_CNT];     // (zeroed ahead of the spectra kernel, which then sets the queue heads)
             size_t asz = sizeof(a);
