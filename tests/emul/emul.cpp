@@ -95,6 +95,25 @@ int emul_plan_dump(const int64_t* seg_len, int P, int C, int L, int groups, int 
     return (int)t.size();
 }
 
+// the same with every option of the assembly engine's planner: XCD ranges, hop-unit block starts (rs), the shared tail queue
+// (tail_pct; *main_out = number of tasks in the per-XCD part)
+int emul_plan_dump_ex(const int64_t* seg_len, int P, int C, int L, int groups, int nwg, int rs, int tail_pct, int32_t* main_out, int32_t* out,
+                      int max_tasks) {
+    std::vector<int64_t> seg_start(P);
+    int64_t s = 0;
+    for (int k = 0; k < P - 1; ++k) { seg_start[k] = s; s += seg_len[k]; }
+    seg_start[P - 1] = s;
+    const int NP = (L + B12 - 1) / B12;
+    std::vector<Task> t;
+    std::vector<int32_t> scratch;
+    int32_t m = -1;
+    plan_seg_lpt(seg_start, P, C, B12, JMAX12, NP, t, scratch, groups, nwg, rs, tail_pct, &m);
+    if (main_out) *main_out = m;
+    const int n = (int)std::min<size_t>(t.size(), (size_t)max_tasks);
+    for (int i = 0; i < n; ++i) { out[4 * i] = t[i].row; out[4 * i + 1] = t[i].chan; out[4 * i + 2] = t[i].j0; out[4 * i + 3] = t[i].nj; }
+    return (int)t.size();
+}
+
 // planner cross-check: the direct O(P*C) segment planner must emit exactly the tasks of the generic (min/max driven) planner
 // whose row actually owns samples; returns 0 when consistent, otherwise a positive diagnostic code
 int emul_plan_compare(const int64_t* seg_len, int P, int C, int L, int64_t* nfast, int64_t* ngeneric) {

@@ -137,3 +137,50 @@ def test_direct_segment_planner_matches_generic_planner(emul):
             rc = emul.emul_plan_compare(P(seg, ip), len(seg) + 1, 3, L, ctypes.byref(nf), ctypes.byref(ng))
             assert rc == 0, (rc, seg.tolist(), L)
             assert 0 < nf.value <= ng.value
+
+
+def test_segment_planner_options_cover_every_sample_once(emul):
+    """plan.h::plan_seg_lpt as the assembly engine uses it -- eight XCD ranges, optional hop-unit block starts (rs), optional shared tail
+    queue: whatever the order, the tasks of a (row, channel) must tile exactly the blocks that contain the row's samples, at most four
+    blocks each, and with a tail the per-XCD part must be a whole number of rounds over the eight ranges."""
+    rng = np.random.default_rng(17)
+    B = 4096
+    i32 = ctypes.POINTER(ctypes.c_int32)
+    for case in range(12):
+        Pn = int(rng.integers(2, 90))
+        C = int(rng.integers(1, 5))
+        L = int(rng.integers(5000, 60000))
+        seg = rng.integers(0, 30000, Pn - 1).astype(np.int64)
+        if case % 3 == 0:
+            seg[rng.integers(0, Pn - 1)] = 0                       # a zero-length segment
+        start = np.concatenate([[0], np.cumsum(seg)])
+        for rs, tail in ((0, 0), (0, 12), (1, 0), (2, 20), (0, 50)):
+            out = np.zeros((200000, 4), np.int32)
+            m = ctypes.c_int32(-7)
+            n = emul.emul_plan_dump_ex(P(seg, ip), Pn, C, L, 8, 256, rs, tail, ctypes.byref(m), P(out, i32), len(out))
+            assert 0 <= n <= len(out)
+            t = out[:n]
+            hop = B >> rs
+            seen = {}
+            for row, chan, j0, nj in t:
+                assert 1 <= nj <= 4 and 0 <= chan < C and 0 <= row < Pn
+                seen.setdefault((row, chan), []).append((j0, nj))
+            for r in range(Pn):
+                a0 = start[r - 1] if r > 0 else start[r]
+                a2 = start[r + 1] if r < Pn - 1 else start[r]
+                for c in range(C):
+                    got = sorted(seen.get((r, c), []))
+                    if a2 <= a0:
+                        assert not got
+                        continue
+                    first = (a0 // hop) * hop                     # first sample of the row's first block
+                    assert got and got[0][0] * hop == first
+                    pos = first
+                    for j0, nj in got:                            # consecutive, no gap, no overlap
+                        assert j0 * hop == pos
+                        pos += nj * B
+                    assert pos >= a2 and pos - B < a2             # ... and exactly up to the block that holds the row's last sample
+            if tail:
+                assert 0 <= m.value <= n and m.value % 8 == 0 and (n < 16 or m.value < n)
+            else:
+                assert m.value == n
