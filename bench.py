@@ -36,6 +36,123 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md); measured copy ceiling 6290 GB/s
 
 
+class GpuTelemetry:
+    """sclk / mclk / power / temperature of one GPU from amdgpu's sysfs (hwmon), read before and after every timed window and by
+    a 4 ms sampler thread during the sustained section: the line then says whether a slow window was a slow CLOCK (power / thermal
+    management of that box) or something else.  Everything is best effort: a missing file gives nulls, never an error."""
+
+    def __init__(self, index=0, pci_bus_id=None):
+        import glob
+        self.dir = None
+        cards = sorted(d for d in glob.glob("/sys/class/drm/card[0-9]*/device") if os.path.exists(os.path.join(d, "pp_dpm_sclk")))
+        pick = None
+        if pci_bus_id:
+            for d in cards:
+                try:
+                    if os.path.basename(os.path.realpath(d)).lower().endswith(pci_bus_id.lower()[-10:]):
+                        pick = d
+                except OSError:
+                    pass
+        if pick is None and cards:
+            pick = cards[index % len(cards)]
+        self.dir = pick
+        self.hwmon = None
+        if pick:
+            hm = sorted(glob.glob(os.path.join(pick, "hwmon", "hwmon*")))
+            self.hwmon = hm[0] if hm else None
+        self.samples = []
+        self._stop = None
+        self._thr = None
+
+    @staticmethod
+    def _read(path):
+        try:
+            with open(path) as f:
+                return f.read()
+        except OSError:
+            return None
+
+    def _num(self, name, scale):
+        if not self.hwmon:
+            return None
+        v = self._read(os.path.join(self.hwmon, name))
+        try:
+            return float(v) * scale
+        except (TypeError, ValueError):
+            return None
+
+    def _dpm(self, name):
+        v = self._read(os.path.join(self.dir, name)) if self.dir else None
+        if not v:
+            return None
+        for line in v.splitlines():
+            if line.rstrip().endswith("*"):
+                try:
+                    return float(line.split(":")[1].strip().lower().split("mhz")[0])
+                except (IndexError, ValueError):
+                    return None
+        return None
+
+    def snap(self):
+        sclk = self._num("freq1_input", 1e-6)
+        mclk = self._num("freq2_input", 1e-6)
+        if sclk is None:
+            sclk = self._dpm("pp_dpm_sclk")
+        if mclk is None:
+            mclk = self._dpm("pp_dpm_mclk")
+        pw = self._num("power1_average", 1e-6)
+        if pw is None:
+            pw = self._num("power1_input", 1e-6)
+        return {"sclk_mhz": sclk, "mclk_mhz": mclk, "power_w": pw, "temp_c": self._num("temp1_input", 1e-3)}
+
+    def start(self, period_s=0.004):
+        import threading
+        self._stop = threading.Event()
+
+        def loop():
+            while not self._stop.is_set():
+                s = self.snap()
+                s["t"] = time.perf_counter()
+                self.samples.append(s)
+                self._stop.wait(period_s)
+        self._thr = threading.Thread(target=loop, daemon=True)
+        self._thr.start()
+
+    def stop(self):
+        if self._thr:
+            self._stop.set()
+            self._thr.join()
+            self._thr = None
+
+    def summary(self, t0=None, t1=None):
+        out = {"source": (self.hwmon or self.dir), "samples": 0}
+        sel = [s for s in self.samples if (t0 is None or s["t"] >= t0) and (t1 is None or s["t"] <= t1)]
+        out["samples"] = len(sel)
+        for k in ("sclk_mhz", "mclk_mhz", "power_w", "temp_c"):
+            v = [s[k] for s in sel if s.get(k) is not None]
+            out[k] = {"min": min(v), "mean": sum(v) / len(v), "max": max(v)} if v else None
+        return out
+
+
+def _pci_id(torch, dev):
+    """'dddd:bb:dd.f' of a torch device, for matching its sysfs node (None when torch does not expose it)"""
+    try:
+        pr = torch.cuda.get_device_properties(dev)
+        return "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+    except Exception:
+        return None
+
+
+def dist_stats(v):
+    """min / median / p90 / max / mean of a list of per-launch durations (ms)"""
+    if not v:
+        return None
+    a = sorted(v)
+    n = len(a)
+    q = lambda f: a[min(n - 1, int(f * (n - 1) + 0.5))]
+    return {"n": n, "min": a[0], "median": q(0.5), "p90": q(0.9), "max": a[-1], "mean": sum(a) / n}
+
+
 def algorithmic_bytes(T, P, C, L):
     """bank read once + x + idx(int64) + w + y write (defined from the boundary signature)."""
     return 4 * P * C * L + 4 * T + 8 * T + 4 * T + 4 * C * T
@@ -187,11 +304,16 @@ def run_cfg2(args, rank, local_rank, world, dev):
         return parallel.barrier_max_seconds(dt, device=dev), y
 
     # ---- cold: W warm-up steps of a fresh process, then K timed steps
+    tel = GpuTelemetry(local_rank, _pci_id(torch, dev))
+    clk0 = tel.snap()
     run_steps(args.warmup)
     torch.cuda.synchronize()
     dt_cold, _ = timed(args.steps)
     # ---- sustained: untimed pre-roll until the clocks have ramped up (the first ~30 renders of a fresh process run 10-15 % slower),
-    #      W warm-up steps again, K timed steps with HIP events around every 2nd launch of the render kernel
+    #      then R windows of [W warm-up steps, K timed steps]; HIP events bracket the render kernel's launches inside every window
+    #      (BENCH_PROF_EVERY = 1: every launch).  `value` is the MEDIAN window (each window times exactly K steps between barriers +
+    #      synchronisations); every window, its per-launch distribution and the clocks around it are printed too, so a disturbed
+    #      window (round 2's driver run: 0.258 ms/step in ONE 5 ms window against 0.195 before and after) shows up as what it is.
     prewarm_ms = float(os.environ.get("BENCH_PREWARM_MS", "80"))
     prewarm_steps = 0
     t_pre = time.perf_counter()
@@ -199,14 +321,45 @@ def run_cfg2(args, rank, local_rank, world, dev):
         run_steps(10)
         torch.cuda.synchronize()
         prewarm_steps += 10
-    run_steps(args.warmup)
-    torch.cuda.synchronize()
-    ops.prof_enable(not os.environ.get("BENCH_NOPROF"), every=int(os.environ.get("BENCH_PROF_EVERY", "2")))
-    dt, y = timed(args.steps)
-    n_os, ms_os = ops.prof_read(0)
-    n_xs, ms_xs = ops.prof_read(1)
-    n_os_all = ops.prof_seen(0)
-    ops.prof_enable(False)
+    prof_every = int(os.environ.get("BENCH_PROF_EVERY", "1"))
+    nwin = max(1, args.windows)
+    tel.start()
+    t_sus0 = time.perf_counter()
+    windows = []
+    y = None
+    for wi in range(nwin):
+        run_steps(args.warmup)
+        torch.cuda.synchronize()
+        ops.prof_enable(not os.environ.get("BENCH_NOPROF"), every=prof_every)
+        c_before = tel.snap()
+        dtw, y = timed(args.steps)
+        c_after = tel.snap()
+        ms_list = ops.prof_list(0)
+        xs_list = ops.prof_list(1)
+        seen = ops.prof_seen(0)
+        ops.prof_enable(False)
+        windows.append({"dt": dtw, "os_ms": ms_list, "xs_ms": xs_list, "seen": seen, "clk_before": c_before, "clk_after": c_after})
+    t_sus1 = time.perf_counter()
+    # ---- informational A/B in the same process: the static task lists (ss_set_task_queue(0)), one window
+    ab_static = None
+    if world == 1 and not os.environ.get("BENCH_NO_AB"):
+        ops.set_task_queue(False)
+        run_steps(args.warmup)
+        torch.cuda.synchronize()
+        ops.prof_enable(True, every=prof_every)
+        dts, _ = timed(args.steps)
+        ab_static = {"ms_per_step": dts / args.steps * 1e3, "kernel_ms": dist_stats(ops.prof_list(0))}
+        ops.prof_enable(False)
+        ops.set_task_queue(os.environ.get("BENCH_STATIC_LISTS") != "1")
+    tel.stop()
+    order = sorted(range(nwin), key=lambda i: windows[i]["dt"])
+    med = windows[order[(nwin - 1) // 2]]                  # the median window (lower median for an even count)
+    dt = med["dt"]
+    all_os = [v for wdw in windows for v in wdw["os_ms"]]
+    all_xs = [v for wdw in windows for v in wdw["xs_ms"]]
+    n_os, ms_os = len(med["os_ms"]), sum(med["os_ms"])
+    n_xs, ms_xs = len(med["xs_ms"]), sum(med["xs_ms"])
+    n_os_all = med["seen"]
     if rank != 0:
         return None
     audio_s = sc.T / sc.fs
@@ -231,7 +384,7 @@ def run_cfg2(args, rank, local_rank, world, dev):
                   f"rendered-audio-sec/sec ({sc.C}-ch, {sc.P}-pt trajectory, {sc.fs // 1000} kHz)",
         "value": value,
         "unit": "rendered-audio-sec/sec",
-        "n_gpus": world,
+        "n_gpus": (args.dist_info or {}).get("distinct_gpus", world),
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3,
@@ -242,13 +395,23 @@ def run_cfg2(args, rank, local_rank, world, dev):
         "data": "synthetic",
         "value_cold": world * args.steps * audio_s / dt_cold,
         "ms_per_step_cold": dt_cold / args.steps * 1e3,
+        "windows": {"count": nwin, "value_is": "median window",
+                    "ms_per_step": [wdw["dt"] / args.steps * 1e3 for wdw in windows],
+                    "value_min": world * args.steps * audio_s / max(wdw["dt"] for wdw in windows),
+                    "value_max": world * args.steps * audio_s / min(wdw["dt"] for wdw in windows),
+                    "kernel_ms_median_per_window": [(dist_stats(wdw["os_ms"]) or {}).get("median") for wdw in windows],
+                    "sclk_mhz_before_after": [[wdw["clk_before"]["sclk_mhz"], wdw["clk_after"]["sclk_mhz"]] for wdw in windows],
+                    "power_w_before_after": [[wdw["clk_before"]["power_w"], wdw["clk_after"]["power_w"]] for wdw in windows]},
+        "clocks": {"at_start": clk0, "sustained_section": tel.summary(t_sus0, t_sus1)},
+        "ab_static_lists": ab_static,
         "config": {"workload": f"{args.config}: single moving source, {sc.C}-mic, {audio_s:.0f} s @ {sc.fs} Hz, "
                                f"{sc.P} trajectory points, {sc.L}-tap RIRs (T={sc.T})",
                    "T": sc.T, "P": sc.P, "C": sc.C, "L": sc.L, "fs": sc.fs,
-                   "entry_point": "ss_convolve_moving_seg_f32", "parallelism": f"scene-sharded x{world}", "task_queue": "dynamic, one per XCD (the default; ss_set_task_queue)",
+                   "entry_point": "ss_convolve_moving_seg_f32", "parallelism": f"scene-sharded x{world}", "distributed": args.dist_info, "task_queue": "dynamic, one per XCD (the default; ss_set_task_queue)",
                    "gather": f"every {ge}th render of every rank to rank 0, overlapped with the next renders" if do_gather else False,
-                   "value_is": "sustained: K timed steps after an untimed pre-roll + W warm-up steps; value_cold = K steps right after the "
-                               "W warm-up steps of the fresh process",
+                   "value_is": f"sustained: the MEDIAN of {nwin} windows, each = W warm-up steps + exactly K timed steps between barrier + "
+                               "synchronize, after an untimed pre-roll (all windows are listed under `windows`); value_cold = K steps right "
+                               "after the W warm-up steps of the fresh process",
                    "prewarm_ms": prewarm_ms, "prewarm_steps": prewarm_steps},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
@@ -258,6 +421,12 @@ def run_cfg2(args, rank, local_rank, world, dev):
                      "algorithmic_bytes_per_launch": bytes_per_launch,
                      "bytes_the_entry_point_touches": render_bytes - 12 * sc.T,       # idx/w (12 T bytes) are implicit in ss_convolve_moving_seg_f32
                      "avg_launch_ms": avg_launch_ms,
+                     "avg_launch_is": f"mean over the {n_os} event-timed launches of the median window (every "
+                                      f"{'launch' if prof_every == 1 else str(prof_every) + '-th launch'} of the timed region is bracketed by HIP events "
+                                      "on the kernel's stream)",
+                     "launch_ms_median_window": dist_stats(med["os_ms"]),
+                     "launch_ms_all_windows": dist_stats(all_os),
+                     "xspec_ms_all_windows": dist_stats(all_xs),
                      "xspec_avg_launch_ms": ms_xs / max(1, n_xs),
                      "timed_launches": n_os, "launches_in_timed_region": n_os_all,
                      "gpu_ms_per_render_kernels": avg_launch_ms * launches_per_render + ms_xs / max(1, n_xs)},
@@ -327,7 +496,7 @@ def run_scenes(args, rank, local_rank, world, dev):
         "metric": "scene-sec/sec (full SonicSet sample: 3 moving + 2 static renders + LUFS + mix, 8-mic, 60 s @ 16 kHz)",
         "value": total * audio_s / dt,
         "unit": "scene-sec/sec",
-        "n_gpus": world, "steps": per_rank, "warmup": args.warmup,
+        "n_gpus": (args.dist_info or {}).get("distinct_gpus", world), "steps": per_rank, "warmup": args.warmup,
         "ms_per_step": dt / per_rank * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.config}: {total} independent SonicSet scenes, {per_rank} per GPU"
@@ -335,11 +504,33 @@ def run_scenes(args, rank, local_rank, world, dev):
                    "scene": "K1 x 5 (3 banks of 200 positions + 2 static IRs, produced inside the timed region, peak normalisation deferred into "
                             "the render), 3 x ss_convolve_moving_seg_div_f32, 2 x ss_convolve_fixed_f32, ss_lufs_norm_batch_f32, ss_mix_f32",
                    "T": spec.T, "P": 200, "C": spec.C, "L": spec.L, "fs": spec.fs, "scenes_total": total,
-                   "dry_signal_pool": len(pool), "gather": gather,
+                   "dry_signal_pool": len(pool), "gather": gather, "distributed": args.dist_info,
                    "gathered_bytes_at_root": int(total * spec.C * spec.T * 4) if gather else 0,
                    "renders_per_second": total * 5 / dt, "rendered_audio_sec_per_sec": total * 5 * audio_s / dt},
         "result_checksum": float(res.double().abs().mean().item()) if res is not None else None,
     }
+
+
+def self_launch(args, torch):
+    """`python bench.py --gpus N` without a launcher: start the N ranks here, one process per GPU (torch.distributed.run, RCCL),
+    and pass their single JSON line through.  Refuses loudly when the node does not have N GPUs -- it never prints a 1-GPU line
+    under an N-GPU label."""
+    import socket
+    import subprocess
+    n = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if n < args.gpus:
+        raise SystemExit(f"--gpus {args.gpus}: this node shows {n} GPU(s) (HIP_VISIBLE_DEVICES={os.environ.get('HIP_VISIBLE_DEVICES')!r}, "
+                         f"CUDA_VISIBLE_DEVICES={os.environ.get('CUDA_VISIBLE_DEVICES')!r}); one process per GPU over RCCL needs {args.gpus}. "
+                         f"Nothing was measured.")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC (RCCL / cross-process device memory on this driver)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("[bench] self-launch: " + " ".join(cmd), file=sys.stderr, flush=True)
+    raise SystemExit(subprocess.call(cmd, env=env))
 
 
 def main():
@@ -353,28 +544,56 @@ def main():
     ap.add_argument("--no-all-cores", action="store_true")
     ap.add_argument("--gather-every", type=int, default=5)
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--windows", type=int, default=7, help="timed K-step windows of the sustained section (value = the median window)")
     args = ap.parse_args()
     if args.cpu_positions == 0:
         args.cpu_seconds = 0
 
     import torch
 
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args, torch)
+
     from sonicsim_amd import build, ops, parallel
 
     rank, local_rank, world = parallel.env_world()
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with `python bench.py --gpus N` (it starts the N ranks "
+                         f"itself) or torchrun --nproc-per-node N ... bench.py --gpus N")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (the HIP path has no CPU fallback)")
+    backend = os.environ.get("SS_DIST_BACKEND") or "nccl"
+    if world > 1 and backend == "nccl" and torch.cuda.device_count() < world:
+        raise SystemExit(f"--gpus {world}: one process per GPU over RCCL needs {world} visible GPUs, this node shows "
+                         f"{torch.cuda.device_count()} (HIP_VISIBLE_DEVICES={os.environ.get('HIP_VISIBLE_DEVICES')!r})")
     if rank == 0:
         build.build()
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    local_dev = local_rank if torch.cuda.device_count() > local_rank else 0       # (the gloo one-GPU harness shares cuda:0)
+    torch.cuda.set_device(local_dev)
+    dev = torch.device("cuda", local_dev)
     parallel.init_process_group()
     import torch.distributed as dist
+    args.dist_info = None
     if world > 1:
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"process group has {dist.get_world_size()} ranks, --gpus says {args.gpus}")
         dist.barrier()
-    ops.init(local_rank)
+        # n_gpus is the number of DISTINCT devices the ranks really sit on (PCI ids gathered from every rank), not WORLD_SIZE
+        ids = [None] * world
+        dist.all_gather_object(ids, (os.uname().nodename, _pci_id(torch, dev) or f"index{local_dev}"))
+        try:
+            rccl = ".".join(str(v) for v in torch.cuda.nccl.version()) if dist.get_backend() == "nccl" else None
+        except Exception:
+            rccl = None
+        args.dist_info = {"backend": dist.get_backend() + (" (= RCCL on ROCm)" if dist.get_backend() == "nccl" else " (test harness: not RCCL)"),
+                          "rccl_version": rccl, "ranks": world, "distinct_gpus": len(set(ids))}
+        if rank == 0:
+            print(f"[bench] {world} ranks, backend {args.dist_info['backend']}, RCCL {rccl}, {len(set(ids))} distinct GPUs: {ids}", file=sys.stderr, flush=True)
+        if dist.get_backend() == "nccl" and len(set(ids)) != world:
+            raise SystemExit(f"{world} ranks share {len(set(ids))} GPUs: one process per GPU is required")
+    ops.init(local_dev)
     out = run_scenes(args, rank, local_rank, world, dev) if args.config in ("cfg3", "cfg4") else run_cfg2(args, rank, local_rank, world, dev)
     if rank == 0:
         print(json.dumps(out), flush=True)

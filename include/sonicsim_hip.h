@@ -242,6 +242,9 @@ int ss_prof_enable(int on);
 int ss_prof_read(int kind, int64_t* launches, double* total_ms);
 /* all launches of `kind` since ss_prof_enable(on != 0), timed or not */
 int ss_prof_seen(int kind, int64_t* launches);
+/* the individual durations (ms, launch order) of the timed launches of `kind`: at most `cap` are written, *launches = how many
+ * there are (bench.py reports min / median / p90 / max of the render kernel over the timed region) */
+int ss_prof_list(int kind, double* ms_out, int64_t cap, int64_t* launches);
 
 #ifdef __cplusplus
 }

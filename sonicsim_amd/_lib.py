@@ -88,6 +88,7 @@ _SIGS = {
     "ss_prof_enable": (ctypes.c_int, [ctypes.c_int]),
     "ss_prof_read": (ctypes.c_int, [ctypes.c_int, c_i64p, c_f64p]),
     "ss_prof_seen": (ctypes.c_int, [ctypes.c_int, c_i64p]),
+    "ss_prof_list": (ctypes.c_int, [ctypes.c_int, c_f64p, ctypes.c_int64, c_i64p]),
 }
 
 EXPORTS = tuple(_SIGS)

@@ -2778,4 +2778,25 @@ int ss_prof_read(int kind, int64_t* launches, double* total_ms) {
     return SS_OK;
 }
 
+int ss_prof_list(int kind, double* ms_out, int64_t cap, int64_t* launches) {
+    if (!launches || cap < 0 || (cap > 0 && !ms_out)) return fail(SS_EINVAL, "bad argument");
+    Ctx* c;
+    int rc = get_ctx(&c);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPCHK(hipDeviceSynchronize());
+    int64_t n = 0;
+    for (auto& e : c->evs) {
+        if (e.kind != kind) continue;
+        if (n < cap) {
+            float ms = 0.0f;
+            HIPCHK(hipEventElapsedTime(&ms, e.a, e.b));
+            ms_out[n] = ms;
+        }
+        ++n;
+    }
+    *launches = n;
+    return SS_OK;
+}
+
 }  // extern "C"

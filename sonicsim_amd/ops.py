@@ -8,6 +8,8 @@ PyTorch is plumbing here (device memory + streams); all arithmetic is in libsoni
 from __future__ import annotations
 
 import ctypes
+import functools
+import threading
 
 import numpy as np
 
@@ -53,13 +55,36 @@ def _ptr(a):
     return ctypes.c_void_p(a.ctypes.data)
 
 
+_tls = threading.local()
+
+
 def _set_device(t):
     """Make the tensor's device current for the HIP calls that follow (the library picks its per-device context from
-    hipGetDevice).  Callers running several GPUs from one process should wrap their calls in ``torch.cuda.device(i)``; with a
-    single device per process (the torchrun layout) this is a no-op."""
+    hipGetDevice).  The caller's current device is restored when the public entry point returns (``_restores_device``), so
+    driving several GPUs from one process never leaks a device switch into the caller's code."""
     import torch
-    if torch.cuda.current_device() != t.device.index:
+    cur = torch.cuda.current_device()
+    if cur != t.device.index:
+        if getattr(_tls, "restore", None) is None:
+            _tls.restore = cur
         torch.cuda.set_device(t.device)
+
+
+def _restores_device(fn):
+    """Decorator of the entry points that call ``_set_device``: put the caller's current device back on the way out."""
+    @functools.wraps(fn)
+    def wrap(*a, **k):
+        depth = getattr(_tls, "depth", 0)
+        _tls.depth = depth + 1
+        try:
+            return fn(*a, **k)
+        finally:
+            _tls.depth = depth
+            if depth == 0 and getattr(_tls, "restore", None) is not None:
+                import torch
+                torch.cuda.set_device(_tls.restore)
+                _tls.restore = None
+    return wrap
 
 
 def init(device: int = -1):
@@ -76,6 +101,7 @@ def _out_ct(out, C, T, dev):
     return out
 
 
+@_restores_device
 def convolve_moving(x, rirs, idx, w, path=None, out=None, validate=True):
     """Row V (SonicSim_moving.py:63-96).  x (T,), rirs (P,C,L), idx (T,) int, w (T,) -> (C,T).
     validate=False (device tensors, assembly engine): the schedule is planned on the device and the call only enqueues work --
@@ -143,6 +169,7 @@ def _check_moving_shapes(x, rirs, idx, w):
         raise ValueError("interp_index / interp_weight must have shape (audio_len,)")
 
 
+@_restores_device
 def convolve_moving_seg(x, rirs, seg_len, path=None, out=None, bank_peak=None):
     """Rows I+V fused (SonicSim_moving.py:42-45 + :63-96): seg_len (P-1,) host ints, sum == T.
     bank_peak (device tensors only): a one-element float32 device tensor -- render with ``rirs / bank_peak``, i.e. the global
@@ -183,6 +210,7 @@ def convolve_moving_seg(x, rirs, seg_len, path=None, out=None, bank_peak=None):
     return y
 
 
+@_restores_device
 def convolve_fixed(x, h, path=None, out=None):
     """Row F (SonicSim_moving.py:47-61).  x (T,) or (1,T); h (C,L) -> (C,T)."""
     lib = _lib.load()
@@ -211,6 +239,7 @@ def convolve_fixed(x, h, path=None, out=None):
     return y
 
 
+@_restores_device
 def rir_bank_synth(delay, dgain, L, fs, rt60, seed, tail_gain=0.05, rho=0.9, device=None, return_peak=False):
     """Row R: synthetic bank (P,C,L) float32.  device=None -> NumPy array; else torch tensor on it.
     return_peak=True -> (bank, peak): max |bank| tracked inside the generating kernel (row G's abs().max() without a second
@@ -243,6 +272,7 @@ def rir_bank_synth(delay, dgain, L, fs, rt60, seed, tail_gain=0.05, rho=0.9, dev
     return bank
 
 
+@_restores_device
 def rir_early_add_(bank, src, mic, pat, room, beta, order, fs):
     """Row R, optional: image-source early reflections of the shoebox ``room`` (3,) added in place onto the device bank (P, C, L).
     src (P, 3), mic (C, 3) in metres inside the box, pat (P, C) channel pattern; 1..order reflections with wall coefficient beta."""
@@ -260,6 +290,7 @@ def rir_early_add_(bank, src, mic, pat, room, beta, order, fs):
     return bank
 
 
+@_restores_device
 def peak_normalize_(a, want_peak=False, check=False):
     """Row G (SonicSim_audio.py:398): in-place a /= abs(a).max().  Returns the peak if asked.
     Degenerate banks behave exactly like the reference's torch expression: an all-zero bank turns into NaN (0/0) and a NaN
@@ -287,6 +318,7 @@ def peak_normalize_(a, want_peak=False, check=False):
     return float(peak.value) if want_peak else None
 
 
+@_restores_device
 def divide_by_(a, divisor):
     """a /= divisor with a divisor that is already known (the peak ``rir_bank_synth(..., return_peak=True)`` returned): the one
     pass that materialises the normalised bank of SonicSim_audio.py:398.  Same IEEE division as ``peak_normalize_``."""
@@ -308,6 +340,7 @@ def divide_by_(a, divisor):
     return a
 
 
+@_restores_device
 def rms_db(x):
     """Row M (movingdatamodule.py:29-32): 10 log10(max(1e-20, mean(x^2))) over all elements."""
     lib = _lib.load()
@@ -322,6 +355,7 @@ def rms_db(x):
     return float(out.value)
 
 
+@_restores_device
 def mix(speaker_wav, noise_wav, sirs, snr, want_gains=True, out=None):
     """Row M (movingdatamodule.py:105-124).  speaker_wav (S,...), noise_wav (N,...) same trailing shape.
     Returns (mix, speaker_wav_scaled, gains).  A contiguous float32 device ``speaker_wav`` is scaled IN PLACE like the reference
@@ -360,6 +394,7 @@ def mix(speaker_wav, noise_wav, sirs, snr, want_gains=True, out=None):
     return out, spk, gains
 
 
+@_restores_device
 def kweighted_block_power(audio, coef, lo, hi, norm, layout_tc=True):
     """Row U device part: z[C][nblocks] (float64).  audio (T,C) if layout_tc else (C,T)."""
     lib = _lib.load()
@@ -390,6 +425,7 @@ def kweighted_block_power(audio, coef, lo, hi, norm, layout_tc=True):
     return z
 
 
+@_restores_device
 def lufs_norm(audio, coef, lo, hi, block_norm, weights, target_lufs, layout_tc=True):
     """Row U in one call (SonicSim_audio.py:68-81): block powers, BS.1770-4 gating, gain and scaling on the device.
     audio (T,), (T,C) / (C,T), or a batch of stems (S,C,T) (channel-first only) with one target per stem.
@@ -438,6 +474,7 @@ def lufs_norm(audio, coef, lo, hi, block_norm, weights, target_lufs, layout_tc=T
     return out, list(r[:, 0]), list(r[:, 1]), list(r[:, 2]), list(r[:, 3])
 
 
+@_restores_device
 def scale(a, gain, want_sums=False):
     """out = gain * a (pyloudnorm.normalize.loudness); optional (sum(out), sum(a)) in float64."""
     lib = _lib.load()
@@ -469,6 +506,16 @@ def prof_seen(kind=0):
     return int(n.value)
 
 
+def prof_list(kind=0):
+    """Durations (ms, launch order) of the timed launches of `kind` since prof_enable(True)."""
+    n = ctypes.c_int64(0)
+    lib = _lib.load()
+    _lib.check(lib.ss_prof_list(int(kind), None, 0, ctypes.byref(n)))
+    buf = (ctypes.c_double * max(1, n.value))()
+    _lib.check(lib.ss_prof_list(int(kind), buf, n.value, ctypes.byref(n)))
+    return [buf[i] for i in range(n.value)]
+
+
 def prof_read(kind=0):
     n = ctypes.c_int64(0)
     ms = ctypes.c_double(0.0)
@@ -482,6 +529,7 @@ def _ptr_table(ptrs):
     return arr
 
 
+@_restores_device
 def mean_channels(x):
     """``wav.mean(dim=0)`` of a (C, T) float32 device tensor (movingdatamodule.py:63, :77) -> (T,)."""
     import torch
@@ -493,6 +541,7 @@ def mean_channels(x):
     return out
 
 
+@_restores_device
 def crop_rms_db(stems, starts, n):
     """compute_mch_rms_dB (movingdatamodule.py:29-32) of crops [start, start + n) of resident stems, all in one launch.
     stems: list of float32 device tensors, each (T,) or (C, T) contiguous, same shape; starts: list of ints.
@@ -514,6 +563,7 @@ def crop_rms_db(stems, starts, n):
     return out.reshape(len(starts), len(stems))
 
 
+@_restores_device
 def mix_batch(speaker_crops, noise_crops, n, sirs, snrs, want_gains=False):
     """movingdatamodule.py:104-124 for B items in one launch sequence.
     speaker_crops[b] = list of S (tensor, start) pairs, noise_crops[b] = list of N pairs (tensors (T,) or (C, T), contiguous float32
@@ -550,6 +600,7 @@ def mix_batch(speaker_crops, noise_crops, n, sirs, snrs, want_gains=False):
     return mix, spk_out, gains
 
 
+@_restores_device
 def crop_sum(first, second, n):
     """movingdatamodule_remix.py:136-146: ``sum(first crops) + sum(second crops)`` without gains.  first / second: lists of
     (tensor (T,), start) on one device; returns (n,) float32."""
@@ -571,6 +622,7 @@ def crop_sum(first, second, n):
     return out
 
 
+@_restores_device
 def overlap_audio(x, delay_samples):
     """enhancement/look2hear/datas/movingdatamodule.py:34-48 on a (T,) or (1, T) float32 device tensor."""
     import torch

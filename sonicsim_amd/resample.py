@@ -47,6 +47,7 @@ def sinc_kernel(orig_freq: int, new_freq: int, lowpass_filter_width: int = 6, ro
     return taps, first, width, orig, new
 
 
+@ops._restores_device
 def resample(waveform, orig_freq, new_freq, lowpass_filter_width: int = 6, rolloff: float = 0.99):
     """waveform (..., L) float32 -- NumPy / CPU tensor (staged through the library) or ROCm tensor (zero copy) -- ->
     (..., ceil(new * L / orig)) of the same kind."""
