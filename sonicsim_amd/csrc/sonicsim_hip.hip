@@ -80,11 +80,23 @@ template <int ABL = 0> __global__ __launch_bounds__(512, 2) void k_os12(RenderPa
 // counter: task-queue heads of the render kernel that follows -- ncnt words, 64 bytes apart, each set to cnt_init
 __global__ __launch_bounds__(512, 2) void k_xspec13(const float* __restrict__ x, int64_t T, const c32* __restrict__ consts,
                                                     c32* __restrict__ Xs, int M, float* __restrict__ yzero, int64_t nzero,
-                                                    int* __restrict__ counter, int ncnt, int cnt_init, const float* __restrict__ xdiv, int rs) {
+                                                    int* __restrict__ counter, int ncnt, int cnt_init, const float* __restrict__ xdiv, int rs,
+                                                    const uint4* __restrict__ plan_src, uint4* __restrict__ plan_dst, int plan_n16) {
     __shared__ __attribute__((aligned(16))) c32 smem[LDS13_C32];
     DevEnv env{smem};
     if (counter && blockIdx.x == 0 && (int)threadIdx.x < ncnt) counter[16 * threadIdx.x] = cnt_init;
+    // the render's plan (segment table + task list, ~31 KB at config 2) sits in pinned host memory; every workgroup moves its slice to
+    // HBM here, the PCIe round trip hidden behind its transform -- the render kernel then never reads across PCIe (round 3: its
+    // ~10 000 scalar loads per render from host memory stalled ONE launch in ~250 for 0.3-0.65 ms, profiles/r03b, and an in-stream
+    // hipMemcpyAsync instead costs 11 us per render, profiles/r03c)
+    uint4 pv = make_uint4(0, 0, 0, 0);
+    const int pi = 4 * ((int)blockIdx.x + (int)gridDim.x * ((int)threadIdx.x >> 2)) + ((int)threadIdx.x & 3);   // 64-byte units dealt round-robin
+    const bool pok = plan_src && pi < plan_n16;                                                                  // to the workgroups: a few PCIe reads each
+    if (pok) pv = plan_src[pi];
     xspec13_body(env, x, T, consts, Xs, (int)blockIdx.x, M, yzero, nzero, xdiv, rs);
+    if (pok) plan_dst[pi] = pv;
+    if (plan_src)       // (a plan larger than the grid's 8 KB per workgroup: the remainder in a strided loop)
+        for (int i = pi + (int)gridDim.x * 512; i < plan_n16; i += (int)gridDim.x * 512) plan_dst[i] = plan_src[i];
 }
 
 // geometry 13 (tvfir13.h): software-pipelined FFT/MAC, one barrier per transform, buffer addressing, dynamic task queue
@@ -1324,7 +1336,8 @@ struct Ctx {
     std::vector<hipEvent_t> ev_pool;      // recycled timing events (creating events costs host time inside the timed loop)
     int os_variant = 3;     // SS_OS_VARIANT: prefetch depth of the render kernel (0, 2, 3) -- tuning knob
     int os_ablate = 0;      // SS_OS_ABLATE: profiling-only ablation mask (results are WRONG when != 0)
-    bool zero_copy = true;  // SS_ZERO_COPY_PLAN=0: upload the plan with a stream-ordered copy instead of device-mapped pinned memory
+    int plan_mode = 2;      // how the assembly engine's plan reaches the GPU: 2 = staged into HBM by the spectra kernel (default), 1 = read in
+                            // place from device-mapped pinned memory by the render kernel, 0 = stream-ordered hipMemcpyAsync (SS_ZERO_COPY_PLAN knob)
     bool xcd_order = true;  // SS_XCD_ORDER=0 disables the XCD-aware task order -- tuning knob
     bool dynq = true;       // default; ss_set_task_queue(0) selects the static lists: per-XCD dynamic task queues (robust when anything else holds compute units; alone as fast as the static lists)
     // host scratch reused across calls
@@ -1384,7 +1397,7 @@ int get_ctx(Ctx** out) {
         if (const char* e = knob("SS_OS_ABLATE")) c->os_ablate = atoi(e);
 #endif
         if (const char* e = knob("SS_XCD_ORDER")) c->xcd_order = atoi(e) != 0;
-        if (const char* e = knob("SS_ZERO_COPY_PLAN")) c->zero_copy = atoi(e) != 0;
+        if (const char* e = knob("SS_ZERO_COPY_PLAN")) c->plan_mode = atoi(e);
         if (const char* e = knob("SS_DYNQ")) c->dynq = atoi(e) != 0;
         c->inited = true;
     }
@@ -1692,9 +1705,14 @@ int render(int mode, const float* x, int64_t T, const float* bank, int32_t P, in
     // The assembly engine reads its plan (28 KB of task descriptors fetched a task ahead by scalar loads + the segment table)
     // straight from the pinned, device-mapped host buffer: no in-stream DMA copy ahead of the kernels (its start-up latency
     // would sit on the critical path of every render).  Other geometries take the copy.
-    const bool zero_copy_plan = g14 && c->zero_copy;
+    const bool xspec_stages_plan = g14 && c->plan_mode == 2;     // default: the spectra kernel moves the plan from pinned host memory to HBM
+    const bool zero_copy_plan = g14 && c->plan_mode == 1;        // (round 1-2 default, now a tuning knob: the render kernel reads the pinned buffer in place)
+    const size_t blob16 = (blob + 15) / 16;
     const char* plan_base;
-    if (zero_copy_plan) {
+    if (xspec_stages_plan) {
+        if ((rc = ws_ensure(c, WS_PLAN, blob16 * 16))) return rc;
+        plan_base = (const char*)c->ws[WS_PLAN];
+    } else if (zero_copy_plan) {
         plan_base = (const char*)pin->host;
     } else {
         if ((rc = ws_ensure(c, WS_PLAN, blob))) return rc;
@@ -1728,7 +1746,12 @@ int render(int mode, const float* x, int64_t T, const float* bank, int32_t P, in
             }
             if (g13 || g14) hipLaunchKernelGGL(k_xspec13, dim3(M + 1), dim3(NT13), 0, stream, dx, T, (const c32*)c->consts13, (c32*)c->ws[WS_XS], M,
                                                dy, (int64_t)C * T, (g13 || qgroups) ? (int*)c->ws[WS_CNT] : (int*)nullptr, g13 ? 1 : qgroups + 1,
-                                               g13 ? 0 : qinit, xdiv, rs);
+                                               g13 ? 0 : qinit, xdiv, rs, xspec_stages_plan ? (const uint4*)pin->host : (const uint4*)nullptr,
+                                               xspec_stages_plan ? (uint4*)c->ws[WS_PLAN] : (uint4*)nullptr, xspec_stages_plan ? (int)blob16 : 0);
+            if (xspec_stages_plan) {       // the ring slot may be rewritten once the spectra kernel has consumed it
+                HIPCHK(hipEventRecord(pin->ev, stream));
+                pin->pending = true;
+            }
             else if (g12) hipLaunchKernelGGL(k_xspec12, dim3(M + 1), dim3(NT12), 0, stream, dx, T, (const c32*)c->consts12, (c32*)c->ws[WS_XS], M,
                                         dy, (int64_t)C * T, (int*)nullptr);
             else hipLaunchKernelGGL(k_xspec, dim3(M + 1), dim3(NT), 0, stream, dx, T, (const c32*)c->consts, (c32*)c->ws[WS_XS], M);

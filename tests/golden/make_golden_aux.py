@@ -340,7 +340,32 @@ def golden_remix():
     np.savez_compressed(os.path.join(HERE, "g12_remix.npz"), **out)
 
 
+# ------------------------------------------------------------------------------------------------ row X
+def golden_fft_conv():
+    """the reference's own fft_conv (SonicSim_audio.py:17-47, the copy SonicSim_rir.py:62-92 is the same code) at EVEN output lengths
+    T + L - 1, where its irfftn-without-length is correct; 1-D and (1, n)-shaped inputs, is_cpu on and off (CPU tensors either way)"""
+    stub("torchaudio")
+    stub("pyloudnorm")
+    rir = stub("SonicSim_rir", render_rir_parallel=None)
+    rir.Receiver = rir.Source = rir.Scene = object
+    ref = load_module("ref_SonicSim_audio_fftconv", os.path.join(REF, "SonicSim-SonicSet", "SonicSim_audio.py"))
+    out = {}
+    cases = [(3001, 1000), (1600, 257), (777, 778), (4, 1)]         # T + L - 1 even
+    for i, (T, L) in enumerate(cases):
+        assert (T + L - 1) % 2 == 0
+        rng = np.random.default_rng(1300 + i)
+        x = rng.standard_normal(T).astype(np.float32)
+        h = (rng.standard_normal(L) * np.exp(-3.0 * np.arange(L) / L)).astype(np.float32)
+        y = ref.fft_conv(torch.from_numpy(x), torch.from_numpy(h))
+        y2 = ref.fft_conv(torch.from_numpy(x).reshape(1, -1), torch.from_numpy(h).reshape(1, -1), is_cpu=True)
+        assert y.shape == (T + L - 1,) and torch.equal(y, y2) and y.dtype == torch.float32
+        out[f"x{i}"], out[f"h{i}"], out[f"y{i}"] = x, h, y.numpy()
+    out["n"] = len(cases)
+    np.savez_compressed(os.path.join(HERE, "g13_fft_conv.npz"), **out)
+
+
 def main():
+    golden_fft_conv()
     golden_rir_combination()
     golden_datamodules()
     golden_assembly()

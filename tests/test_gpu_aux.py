@@ -316,3 +316,55 @@ def test_provider_early_reflections_keep_the_direct_path(gpu):
     first = np.round(16000 * d / 343.0).astype(int)
     for p in range(3):                                                                     # nothing arrives before the direct path
         assert float(diff[p, 0, : first[p]].max()) == 0.0
+
+
+def test_fft_conv_against_the_references_own_output(gpu):
+    """Row X pinned: tests/golden/g13_fft_conv.npz holds outputs of the reference's fft_conv (SonicSim_audio.py:17-47 = SonicSim_rir.py:62-92,
+    run unmodified by make_golden_aux.py) at even T + L - 1, where its irfftn is well defined; the HIP path (host and device tensors,
+    1-D and (1, n) shapes) agrees with them to float32 round-off."""
+    from sonicsim_amd import SonicSim_audio as A
+    from util import golden
+    g = golden("g13_fft_conv.npz")
+    for i in range(int(g["n"])):
+        x, h, want = g[f"x{i}"], g[f"h{i}"], g[f"y{i}"]
+        for sig, ker in ((torch.from_numpy(x), torch.from_numpy(h)), (torch.from_numpy(x).to(gpu), torch.from_numpy(h).to(gpu)),
+                         (torch.from_numpy(x).reshape(1, -1).to(gpu), torch.from_numpy(h).reshape(1, -1).to(gpu))):
+            got = A.fft_conv(sig, ker)
+            assert got.shape == want.shape and got.dtype == torch.float32
+            assert rel_rms(got.cpu().numpy(), want) < 2e-6, i
+
+
+def test_generate_rir_combination_product_glue_on_ragged_irs(gpu, monkeypatch):
+    """Row G, the PRODUCT's glue (not the oracle): sonicsim_amd.SonicSim_audio.generate_rir_combination with its provider replaced by
+    g9's ragged-length one -- pair order handed to the provider, clip_all to the shortest IR, stack, reshape, global peak division --
+    bit for bit against the bank the reference's own generate_rir_combination (SonicSim_audio.py:342-400) produced, for CPU tensors
+    (host-pointer mode of ss_peak_normalize_f32) and ROCm tensors."""
+    from sonicsim_amd import SonicSim_audio as A
+    from util import golden, golden_ir
+    g = golden("g9_rir_combination.npz")
+    cases = [(0, 7, 1, [90], 4), (1, 3, 2, [0, 90], 2), (2, 2, 1, [90], 1)]          # make_golden_aux.py::golden_rir_combination
+    for on_gpu in (False, True):
+        for case, S, R, rots, C in cases:
+            calls = []
+
+            def provider(room_list, source_position_list, receiver_position_list, mic_array_list=None, filename_list=None,
+                         receiver_rotation_list=None, batch_size=64, sample_rate=16000, use_default_material=False,
+                         channel_type="Ambisonics", channel_order=1, device=None):
+                calls.append(dict(src=list(source_position_list), rcv=list(receiver_position_list), rot=list(receiver_rotation_list),
+                                  channel_order=channel_order, rooms=list(room_list)))
+                irs = [torch.from_numpy(golden_ir(case, i, C)) for i in range(len(room_list))]
+                return [t.to(gpu) for t in irs] if on_gpu else irs
+
+            monkeypatch.setattr(A, "render_rir_parallel", provider)
+            srcs = [[float(s), 0.5, 1.0] for s in range(S)]
+            rcvs = [[10.0 + r, 0.5, 2.0] for r in range(R)]
+            bank = A.generate_rir_combination("room", srcs, rcvs, rots, None, "CustomArrayIR" if C > 2 else "Mono",
+                                              device=gpu if on_gpu else None)
+            assert bank.dtype == torch.float32 and bank.is_cuda == on_gpu
+            assert len({golden_ir(case, i, C).shape[1] for i in range(S * R)}) > 1            # the IRs really are ragged
+            assert np.array_equal(bank.cpu().numpy(), g[f"bank{case}"]), (case, on_gpu)
+            assert len(calls) == 1 and calls[0]["rooms"] == ["room"] * (S * R)
+            assert np.array_equal(np.array(calls[0]["src"], dtype=np.float64), g[f"src_order{case}"])
+            assert np.array_equal(np.array(calls[0]["rcv"], dtype=np.float64), g[f"rcv_order{case}"])
+            assert np.array_equal(np.array(calls[0]["rot"], dtype=np.float64), g[f"rot_order{case}"])
+            assert calls[0]["channel_order"] == int(g[f"channel_order{case}"])

@@ -5,9 +5,10 @@
         SonicSim_moving.py:86-94) evaluated 16 positions at a time (bitwise the same as the unchunked form, ~15 s on the box).
   cfg3  one full SonicSet sample at cfg2 shapes (3 moving + 2 static renders, 5 loudness normalisations, 2-speaker + noise mix),
         stage by stage against the oracles.
-  cfg5  FOA 120 s @ 48 kHz, 500 points, 96000 taps: 50 segments in five stretches across the render (every row there spans more
-        than four 4096-sample blocks, i.e. takes the split-task path), against the reference algorithm restricted to the
-        positions those segments use (rows of oaconvolve are independent: exactly the reference's arithmetic for those samples).
+  cfg5  FOA 120 s @ 48 kHz, 500 points, 96000 taps: the WHOLE output (all 499 segments, 4 x 5 760 000 samples) against the reference
+        algorithm with its 500 positions spread over the host cores (oracle/allcores.py: the same oaconvolve rows, bitwise the
+        one-shot result; ~100 core-seconds, 46 GB of intermediate if done in one piece), plus the 50-segment spot check of
+        round 1-2 (76 % of the rows span more than four 4096-sample blocks, i.e. take the split-task path).
 Gate: RMS(y - y_ref) / RMS(y_ref) <= 1e-4 per channel and overall (north star)."""
 import numpy as np
 import pytest
@@ -109,3 +110,23 @@ def test_cfg5_fifty_segments(gpu):
         print(f"cfg5 segments {k0}..{k1 - 1}: rel RMS {r:.3e}")
         checked += int((seg[k0:k1] > 0).sum())
     assert checked >= 45
+
+
+def test_cfg5_whole_output_vs_oracle(gpu):
+    """BASELINE.json config 5 end to end: every sample of every channel of the 120 s / 48 kHz / 500-point / 96000-tap render against the
+    reference algorithm (SonicSim_moving.py:86-94: oaconvolve of EVERY position over the whole length, gather, lerp) evaluated by a pool
+    of host processes, two positions per job."""
+    from oracle import allcores
+    from sonicsim_amd import ops, synth
+    sc = synth.make_scene("cfg5", scene=0)
+    seg = synth.scene_segments(sc, 0)
+    bank, _ = _bank(ops, sc, gpu)
+    x = torch.from_numpy(sc.x).to(gpu)
+    y = ops.convolve_moving_seg(x, bank, seg)
+    torch.cuda.synchronize()
+    assert y.shape == (4, 5760000)
+    idx, w = moving.expand_segments(seg)
+    ref, dt, procs, jobs = allcores.convolve_moving_receiver_all_cores(sc.x, bank.cpu().numpy(), idx, w, positions_per_job=2)
+    r = assert_parity(y.cpu().numpy(), ref)
+    print(f"cfg5 whole output: rel RMS {r:.3e}  (reference algorithm: {dt:.1f} s on {procs} processes, {jobs} jobs)")
+    assert np.abs(y.cpu().numpy() - ref).max() <= 5e-3 * np.sqrt(np.mean(ref.astype(np.float64) ** 2))

@@ -149,3 +149,15 @@ def test_remix_find_overlap_region_and_eval_bitwise():
         torch.manual_seed(71 + j)
         mix, spk, _ = D.remix_test_eval_getitem(load, str(g["ev_folder"]), 16000, 1, True, nt)
         assert np.array_equal(mix.numpy(), g[f"ev_mix{j}"]) and np.array_equal(spk.numpy(), g[f"ev_spk{j}"])
+
+
+# ------------------------------------------------------------------------------------------------ row X
+def test_fft_conv_golden_is_the_full_linear_convolution():
+    """the oracle of row X is SciPy's fftconvolve (float64); at even T + L - 1 the reference's own fft_conv output (g13, produced by
+    SonicSim_audio.py:17-47 unmodified) IS that convolution to float32 round-off -- which pins the oracle to the reference"""
+    from scipy import signal
+    g = golden("g13_fft_conv.npz")
+    for i in range(int(g["n"])):
+        want = signal.fftconvolve(g[f"x{i}"].astype(np.float64), g[f"h{i}"].astype(np.float64), mode="full")
+        assert g[f"y{i}"].shape == want.shape and g[f"y{i}"].dtype == np.float32
+        assert np.sqrt(np.mean((g[f"y{i}"] - want) ** 2)) <= 1e-6 * np.sqrt(np.mean(want ** 2))
