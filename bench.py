@@ -289,10 +289,10 @@ def run_cfg2(args, rank, local_rank, world, dev):
     torch.cuda.synchronize()
     dt_cold, _ = timed(args.steps)
     # ---- sustained: untimed pre-roll until the clocks have ramped up (the first ~30 renders of a fresh process run 10-15 % slower),
-    #      then R windows of [W warm-up steps, K timed steps]; HIP events bracket the render kernel's launches inside every window
-    #      (BENCH_PROF_EVERY = 1: every launch).  `value` is the MEDIAN window (each window times exactly K steps between barriers +
-    #      synchronisations); every window, its per-launch distribution and the clocks around it are printed too, so a disturbed
-    #      window (round 2's driver run: 0.258 ms/step in ONE 5 ms window against 0.195 before and after) shows up as what it is.
+    #      then R value windows of [W warm-up steps, K timed steps] interleaved with event windows.  `value` is the MEDIAN value window
+    #      (each window times exactly K steps between barriers + synchronisations); every window and the clocks around it are printed
+    #      too, so a disturbed window (round 2's driver run: 0.258 ms/step in ONE 5 ms window against 0.195 before and after -- one
+    #      launch that stalled 0.6 ms on a PCIe read of the plan, profiles/r03a-b) shows up as what it is.
     prewarm_ms = float(os.environ.get("BENCH_PREWARM_MS", "80"))
     prewarm_steps = 0
     t_pre = time.perf_counter()
@@ -302,49 +302,70 @@ def run_cfg2(args, rank, local_rank, world, dev):
         prewarm_steps += 10
     prof_every = int(os.environ.get("BENCH_PROF_EVERY", "1"))
     nwin = max(1, args.windows)
+    nevw = max(1, int(os.environ.get("BENCH_EVENT_WINDOWS", "4")))
     tel.start()
     t_sus0 = time.perf_counter()
-    windows = []
+    windows, ev_windows = [], []
     y = None
-    for wi in range(nwin):
+
+    def window(events):
         run_steps(args.warmup)
         torch.cuda.synchronize()
-        ops.prof_enable(not os.environ.get("BENCH_NOPROF"), every=prof_every)
+        if events:
+            ops.prof_enable(True, every=prof_every)
         c_before = tel.snap()
-        dtw, y = timed(args.steps)
+        dtw, yy = timed(args.steps)
         c_after = tel.snap()
-        ms_list = ops.prof_list(0)
-        xs_list = ops.prof_list(1)
-        seen = ops.prof_seen(0)
-        ops.prof_enable(False)
-        windows.append({"dt": dtw, "os_ms": ms_list, "xs_ms": xs_list, "seen": seen, "clk_before": c_before, "clk_after": c_after})
+        rec = {"dt": dtw, "clk_before": c_before, "clk_after": c_after, "os_ms": [], "xs_ms": [], "seen": 0}
+        if events:
+            rec.update(os_ms=ops.prof_list(0), xs_ms=ops.prof_list(1), seen=ops.prof_seen(0))
+            ops.prof_enable(False)
+        return rec, yy
+
+    # value windows carry NO events: a HIP event pair costs 4-5 us per bracketed launch (profiles/r03e: 0.193 ms/step without, 0.204 with
+    # every 2nd, 0.211 with every launch bracketed).  The event windows (same K steps, every launch of the render kernel and of the
+    # spectra kernel bracketed on the kernels' stream) are interleaved with them in the same process and give the per-launch
+    # distribution + the roofline figure; their own ms/step is printed next to the value windows'.
+    order_plan = []
+    for wi in range(max(nwin, nevw)):
+        if wi < nwin:
+            order_plan.append(False)
+        if wi < nevw:
+            order_plan.append(not os.environ.get("BENCH_NOPROF"))
+    for ev in order_plan:
+        rec, yy = window(ev)
+        (ev_windows if ev else windows).append(rec)
+        y = yy
+    if not ev_windows:
+        ev_windows = [dict(windows[0])]
+    if not windows:
+        windows = [dict(w) for w in ev_windows]
+    nwin = len(windows)
     t_sus1 = time.perf_counter()
     # ---- informational A/B in the same process: the static task lists (ss_set_task_queue(0)), one window
     ab_static = None
     if world == 1 and not os.environ.get("BENCH_NO_AB"):
         ops.set_task_queue(False)
-        run_steps(args.warmup)
-        torch.cuda.synchronize()
-        ops.prof_enable(True, every=prof_every)
-        dts, _ = timed(args.steps)
-        ab_static = {"ms_per_step": dts / args.steps * 1e3, "kernel_ms": dist_stats(ops.prof_list(0))}
-        ops.prof_enable(False)
+        rec_v, _ = window(False)
+        rec_e, _ = window(True)
+        ab_static = {"ms_per_step": rec_v["dt"] / args.steps * 1e3, "ms_per_step_with_events": rec_e["dt"] / args.steps * 1e3,
+                     "kernel_ms": dist_stats(rec_e["os_ms"])}
         ops.set_task_queue(os.environ.get("BENCH_STATIC_LISTS") != "1")
     tel.stop()
     order = sorted(range(nwin), key=lambda i: windows[i]["dt"])
-    med = windows[order[(nwin - 1) // 2]]                  # the median window (lower median for an even count)
-    dt = med["dt"]
-    all_os = [v for wdw in windows for v in wdw["os_ms"]]
-    all_xs = [v for wdw in windows for v in wdw["xs_ms"]]
-    n_os, ms_os = len(med["os_ms"]), sum(med["os_ms"])
-    n_xs, ms_xs = len(med["xs_ms"]), sum(med["xs_ms"])
-    n_os_all = med["seen"]
+    dt = windows[order[(nwin - 1) // 2]]["dt"]             # the median value window (lower median for an even count)
+    all_os = [v for wdw in ev_windows for v in wdw["os_ms"]]
+    all_xs = [v for wdw in ev_windows for v in wdw["xs_ms"]]
+    n_os, ms_os = len(all_os), sum(all_os)
+    n_xs, ms_xs = len(all_xs), sum(all_xs)
+    n_os_all = sum(wdw["seen"] for wdw in ev_windows)
+    steps_ev = args.steps * len(ev_windows)
     if rank != 0:
         return None
     audio_s = sc.T / sc.fs
     value = world * args.steps * audio_s / dt
     render_bytes = algorithmic_bytes(sc.T, sc.P, sc.C, sc.L)
-    launches_per_render = (n_os_all if n_os_all else n_os) / max(1, args.steps)
+    launches_per_render = (n_os_all if n_os_all else n_os) / max(1, steps_ev)
     avg_launch_ms = ms_os / max(1, n_os)
     bytes_per_launch = render_bytes / max(1.0, launches_per_render)
     achieved = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
@@ -374,13 +395,16 @@ def run_cfg2(args, rank, local_rank, world, dev):
         "data": "synthetic",
         "value_cold": world * args.steps * audio_s / dt_cold,
         "ms_per_step_cold": dt_cold / args.steps * 1e3,
-        "windows": {"count": nwin, "value_is": "median window",
+        "windows": {"count": nwin, "value_is": "median of the value windows (no HIP events inside them)",
                     "ms_per_step": [wdw["dt"] / args.steps * 1e3 for wdw in windows],
                     "value_min": world * args.steps * audio_s / max(wdw["dt"] for wdw in windows),
                     "value_max": world * args.steps * audio_s / min(wdw["dt"] for wdw in windows),
-                    "kernel_ms_median_per_window": [(dist_stats(wdw["os_ms"]) or {}).get("median") for wdw in windows],
                     "sclk_mhz_before_after": [[wdw["clk_before"]["sclk_mhz"], wdw["clk_after"]["sclk_mhz"]] for wdw in windows],
-                    "power_w_before_after": [[wdw["clk_before"]["power_w"], wdw["clk_after"]["power_w"]] for wdw in windows]},
+                    "power_w_before_after": [[wdw["clk_before"]["power_w"], wdw["clk_after"]["power_w"]] for wdw in windows],
+                    "event_windows": {"count": len(ev_windows), "interleaved_with_the_value_windows": True,
+                                      "ms_per_step": [wdw["dt"] / args.steps * 1e3 for wdw in ev_windows],
+                                      "kernel_ms_median_per_window": [(dist_stats(wdw["os_ms"]) or {}).get("median") for wdw in ev_windows],
+                                      "event_pairs_per_step": 2 if prof_every == 1 else 2.0 / prof_every}},
         "clocks": {"at_start": clk0, "sustained_section": tel.summary(t_sus0, t_sus1)},
         "ab_static_lists": ab_static,
         "config": {"workload": f"{args.config}: single moving source, {sc.C}-mic, {audio_s:.0f} s @ {sc.fs} Hz, "
@@ -389,8 +413,9 @@ def run_cfg2(args, rank, local_rank, world, dev):
                    "entry_point": "ss_convolve_moving_seg_f32", "parallelism": f"scene-sharded x{world}", "distributed": args.dist_info, "task_queue": "dynamic, one per XCD (the default; ss_set_task_queue)",
                    "gather": f"every {ge}th render of every rank to rank 0, overlapped with the next renders" if do_gather else False,
                    "value_is": f"sustained: the MEDIAN of {nwin} windows, each = W warm-up steps + exactly K timed steps between barrier + "
-                               "synchronize, after an untimed pre-roll (all windows are listed under `windows`); value_cold = K steps right "
-                               "after the W warm-up steps of the fresh process",
+                               "synchronize, after an untimed pre-roll (all windows are listed under `windows`; the HIP events behind `roofline` "
+                               "sit in separate, interleaved windows of the same K steps); value_cold = K steps right after the W warm-up steps "
+                               "of the fresh process",
                    "prewarm_ms": prewarm_ms, "prewarm_steps": prewarm_steps},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
@@ -400,10 +425,9 @@ def run_cfg2(args, rank, local_rank, world, dev):
                      "algorithmic_bytes_per_launch": bytes_per_launch,
                      "bytes_the_entry_point_touches": render_bytes - 12 * sc.T,       # idx/w (12 T bytes) are implicit in ss_convolve_moving_seg_f32
                      "avg_launch_ms": avg_launch_ms,
-                     "avg_launch_is": f"mean over the {n_os} event-timed launches of the median window (every "
-                                      f"{'launch' if prof_every == 1 else str(prof_every) + '-th launch'} of the timed region is bracketed by HIP events "
-                                      "on the kernel's stream)",
-                     "launch_ms_median_window": dist_stats(med["os_ms"]),
+                     "avg_launch_is": f"mean over the {n_os} event-timed launches of the {len(ev_windows)} event windows (every "
+                                      f"{'launch' if prof_every == 1 else str(prof_every) + '-th launch'} of those timed regions is bracketed by HIP "
+                                      "events on the kernel's stream)",
                      "launch_ms_all_windows": dist_stats(all_os),
                      "xspec_ms_all_windows": dist_stats(all_xs),
                      "xspec_avg_launch_ms": ms_xs / max(1, n_xs),

@@ -42,6 +42,7 @@ extern "C" {
 #define SS_FLAG_GEOM_13 0x200u    /* overlap-save engine: force the software-pipelined B = 4096 geometry (tvfir13.h; default for long filters) */
 #define SS_FLAG_GEOM_ASM 0x400u   /* overlap-save engine: force the hand-scheduled gfx950 assembly kernel (segment / fixed schedules) */
 #define SS_FLAG_LAYOUT_TC 0x100u  /* audio is [T][C] instead of [C][T] (loudness / mix calls) */
+#define SS_FLAG_META_DEVICE 0x1000u /* ss_rir_bank_synth*_f32 with SS_FLAG_DEVICE_PTR: SsRirParams.delay / .dgain are DEVICE pointers (no staging copy) */
 #define SS_FLAG_ASYNC_PLAN 0x800u /* ss_convolve_moving_f32 with device pointers: plan the explicit schedule on the device (no host synchronisation) */
 
 int ss_version(void);

@@ -21,6 +21,7 @@ FLAG_LAYOUT_TC = 0x100
 FLAG_GEOM_13 = 0x200
 FLAG_GEOM_ASM = 0x400
 FLAG_ASYNC_PLAN = 0x800
+FLAG_META_DEVICE = 0x1000
 
 SS_EINVAL, SS_EHIP, SS_ENOMEM, SS_ENODEV = -1, -2, -3, -4
 

@@ -81,7 +81,8 @@ template <int ABL = 0> __global__ __launch_bounds__(512, 2) void k_os12(RenderPa
 __global__ __launch_bounds__(512, 2) void k_xspec13(const float* __restrict__ x, int64_t T, const c32* __restrict__ consts,
                                                     c32* __restrict__ Xs, int M, float* __restrict__ yzero, int64_t nzero,
                                                     int* __restrict__ counter, int ncnt, int cnt_init, const float* __restrict__ xdiv, int rs,
-                                                    const uint4* __restrict__ plan_src, uint4* __restrict__ plan_dst, int plan_n16) {
+                                                    const uint4* __restrict__ plan_src, uint4* __restrict__ plan_dst, int plan_n16,
+                                                    const int32_t* __restrict__ fail_flag) {
     __shared__ __attribute__((aligned(16))) c32 smem[LDS13_C32];
     DevEnv env{smem};
     if (counter && blockIdx.x == 0 && (int)threadIdx.x < ncnt) counter[16 * threadIdx.x] = cnt_init;
@@ -93,7 +94,11 @@ __global__ __launch_bounds__(512, 2) void k_xspec13(const float* __restrict__ x,
     const int pi = 4 * ((int)blockIdx.x + (int)gridDim.x * ((int)threadIdx.x >> 2)) + ((int)threadIdx.x & 3);   // 64-byte units dealt round-robin
     const bool pok = plan_src && pi < plan_n16;                                                                  // to the workgroups: a few PCIe reads each
     if (pok) pv = plan_src[pi];
-    xspec13_body(env, x, T, consts, Xs, (int)blockIdx.x, M, yzero, nzero, xdiv, rs);
+    // SS_FLAG_ASYNC_PLAN: k_plan_explicit (earlier on this stream) found the schedule too irregular for its task buffer and planned
+    // nothing -- y is then filled with NaN instead of zeros: the failure cannot pass as valid silence even if nobody polls
+    // ss_async_status (word 2 of the status record is written by every planner run; words 0-1 are the latched error)
+    const float fill = (fail_flag && fail_flag[2] != 0) ? __builtin_nanf("") : 0.0f;
+    xspec13_body(env, x, T, consts, Xs, (int)blockIdx.x, M, yzero, nzero, xdiv, rs, fill);
     if (pok) plan_dst[pi] = pv;
     if (plan_src)       // (a plan larger than the grid's 8 KB per workgroup: the remainder in a strided loop)
         for (int i = pi + (int)gridDim.x * 512; i < plan_n16; i += (int)gridDim.x * 512) plan_dst[i] = plan_src[i];
@@ -252,6 +257,7 @@ __global__ __launch_bounds__(1024) void k_plan_explicit(PlanDevArgs a) {
     }
     __syncthreads();
     long long nrow = block_exclusive_scan(a.rcount, a.P, sh);
+    if (tid == 0) a.status[2] = nrow > a.cap_rows ? 1 : 0;      // per call (not latched): the spectra kernel of THIS render fills y with NaN
     if (nrow > a.cap_rows) {
         if (tid == 0 && atomicCAS(&a.status[0], 0, 2) == 0) a.status[1] = (int32_t)(nrow < INT32_MAX ? nrow : INT32_MAX);
         nrow = 0;                                   // render nothing rather than part of the schedule
@@ -355,20 +361,25 @@ __device__ __forceinline__ uint32_t hash32(uint32_t seed, uint32_t stream, uint6
     uint32_t h = fmix32((uint32_t)(ctr >> 32) ^ k);
     return fmix32((uint32_t)ctr ^ h);
 }
-__device__ __forceinline__ float unit24(uint32_t h) { return ((float)(h >> 8) + 0.5f) * 5.9604644775390625e-8f; }
-// Box-Muller on two 24-bit uniforms with the hardware transcendentals (v_log_f32 = log2, v_cos_f32 takes revolutions):
-// sqrt(-2 ln u1) cos(2 pi u2)
-__device__ __forceinline__ float box_muller(float u1, float u2) {
-    return __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1)) * __builtin_amdgcn_cosf(u2);
+__device__ __forceinline__ float unit24(uint32_t h) { return __builtin_fmaf((float)(h >> 8), 5.9604644775390625e-8f, 2.98023223876953125e-8f); }   // (k + 0.5) 2^-24
+// Box-Muller on two 24-bit uniforms with the hardware transcendentals (v_log_f32 = log2, v_cos_f32 / v_sin_f32 take revolutions).
+// BOTH branches are used (round 3): the pair of taps with global counters (2 i, 2 i + 1) shares one (u1, u2) = hash(seed, 1 | 2, i):
+//     g[2 i] = sqrt(-2 ln u1) cos(2 pi u2),   g[2 i + 1] = sqrt(-2 ln u1) sin(2 pi u2)
+// (independent standard normals), i.e. one hash pair, one log2 and one sqrt per TWO taps (oracle/rir_synth.py::gauss is the definition).
+__device__ __forceinline__ void box_muller2(float u1, float u2, float& g0, float& g1) {
+    const float r = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));
+    g0 = r * __builtin_amdgcn_cosf(u2);
+    g1 = r * __builtin_amdgcn_sinf(u2);
 }
 
-// FAST32: the whole bank has fewer than 2^32 samples, so the high counter word is 0 for every sample and the first
-// mixing round of hash32 is one constant per stream (computed once per thread).  V consecutive taps per thread (V = 4 when
-// L % 4 == 0: one 16-byte store per position, four independent hash / Box-Muller chains in flight).  peak_bits (may be null):
-// bit pattern of max |bank| over the whole bank (non-negative floats order like their bit patterns) -- row G's abs().max()
-// for free.
+// FAST32: the bank has fewer than 2^33 samples, so the high word of every PAIR counter is 0 and the first mixing round of hash32 is one
+// constant per stream.  V consecutive taps per thread; V = 2 or 4 needs an even L (then every thread's first counter is even at every
+// position and its taps are whole pairs); V = 1 evaluates its pair's hash per tap (odd L).  The chain over the positions is sequential,
+// so the parallelism is C * L / V threads: two taps per thread give a config-2 bank 3 000 waves for the 1 024 SIMDs.
+// peak_bits (may be null): max |bank| over the whole bank -- row G's abs().max() for free; slots: 1 + gridDim.x words of workspace.
 template <bool FAST32, int V>
-__global__ __launch_bounds__(256) void k_rir_synth(RirDev p, float* __restrict__ bank, unsigned int* __restrict__ peak_bits) {
+__global__ __launch_bounds__(256) void k_rir_synth(RirDev p, float* __restrict__ bank, unsigned int* __restrict__ peak_bits,
+                                                   unsigned int* __restrict__ slots) {
     const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * V;
     const int64_t CL = (int64_t)p.C * p.L;
     const bool live = i < CL;
@@ -385,29 +396,42 @@ __global__ __launch_bounds__(256) void k_rir_synth(RirDev p, float* __restrict__
     float* out = bank + ii;
     const int32_t* dl = p.delay + c;
     const float* dg = p.dgain + c;
+    int d_next = dl[0];
     for (int q = 0; q < p.P; ++q) {
-        const int d = dl[(int64_t)q * p.C];
-        const float dgain = dg[(int64_t)q * p.C];
+        const int d = d_next;                                        // this position's direct-path delay was requested an iteration ago
+        if (q + 1 < p.P) d_next = dl[(int64_t)(q + 1) * p.C];
+        float g[V];
+        if (V == 1) {
+            const uint64_t pr = ctr >> 1;
+            const uint32_t a1 = FAST32 ? fmix32((uint32_t)pr ^ h1c) : fmix32((uint32_t)pr ^ fmix32((uint32_t)(pr >> 32) ^ k1));
+            const uint32_t a2 = FAST32 ? fmix32((uint32_t)pr ^ h2c) : fmix32((uint32_t)pr ^ fmix32((uint32_t)(pr >> 32) ^ k2));
+            float g0, g1;
+            box_muller2(unit24(a1), unit24(a2), g0, g1);
+            g[0] = (ctr & 1) ? g1 : g0;
+        } else {
+#pragma unroll
+            for (int v = 0; v < V; v += 2) {
+                const uint64_t pr = (ctr + (uint64_t)v) >> 1;
+                const uint32_t a1 = FAST32 ? fmix32((uint32_t)pr ^ h1c) : fmix32((uint32_t)pr ^ fmix32((uint32_t)(pr >> 32) ^ k1));
+                const uint32_t a2 = FAST32 ? fmix32((uint32_t)pr ^ h2c) : fmix32((uint32_t)pr ^ fmix32((uint32_t)(pr >> 32) ^ k2));
+                box_muller2(unit24(a1), unit24(a2), g[v], g[v + (V > 1 ? 1 : 0)]);
+            }
+        }
         float val[V];
 #pragma unroll
         for (int v = 0; v < V; ++v) {
-            const uint64_t cv = ctr + (uint64_t)v;
-            uint32_t a1, a2;
-            if (FAST32) {
-                a1 = fmix32((uint32_t)cv ^ h1c);
-                a2 = fmix32((uint32_t)cv ^ h2c);
-            } else {
-                a1 = fmix32((uint32_t)cv ^ fmix32((uint32_t)(cv >> 32) ^ k1));
-                a2 = fmix32((uint32_t)cv ^ fmix32((uint32_t)(cv >> 32) ^ k2));
-            }
-            const float g = box_muller(unit24(a1), unit24(a2));
-            n[v] = (q == 0) ? g : (p.rho * n[v] + p.srho * g);
+            n[v] = (q == 0) ? g[v] : (p.rho * n[v] + p.srho * g[v]);
             const int t = t0 + v;
-            float x = (t > d) ? te[v] * n[v] : 0.0f;
-            if (t == d) x += dgain;
-            val[v] = x;
-            peak = fmaxf(peak, fabsf(x));
+            val[v] = (t > d) ? te[v] * n[v] : 0.0f;
         }
+        if ((unsigned)(d - t0) < (unsigned)V) {                      // the direct-path impulse falls on one of this thread's taps: one thread
+            const float dgain = dg[(int64_t)q * p.C];                // per (position, channel) -- a rarely taken branch, not selects per tap
+#pragma unroll
+            for (int v = 0; v < V; ++v)
+                if (t0 + v == d) val[v] += dgain;
+        }
+#pragma unroll
+        for (int v = 0; v < V; ++v) peak = fmaxf(peak, fabsf(val[v]));
         if (live) {
             if (V == 4) *reinterpret_cast<float4*>(out) = make_float4(val[0], val[1], val[2], val[3]);
             else if (V == 2) *reinterpret_cast<float2*>(out) = make_float2(val[0], val[V - 1]);
@@ -418,15 +442,40 @@ __global__ __launch_bounds__(256) void k_rir_synth(RirDev p, float* __restrict__
         out += CL;
         ctr += (uint64_t)CL;
     }
-    if (peak_bits) {      // one atomic per workgroup, and only when it can raise the maximum: atomics on ONE address serialise (~12 ns each)
+    if (peak_bits) {
+        // max |bank| without an initialised result word (a hipMemsetAsync ahead of the kernel is 4 us + a 6 us boundary, profiles/r03g):
+        // every workgroup publishes its maximum in its own slot (write-through store), draws an arrival ticket, and the LAST arriver
+        // reduces the slots, stores the result and resets the ticket for the next launch (slot 0 = ticket, zeroed when allocated).
         __shared__ float wmax[4];
+        __shared__ int is_last;
         if (!live) peak = 0.0f;
         for (int o = 32; o > 0; o >>= 1) peak = fmaxf(peak, __shfl_xor(peak, o));
         if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = peak;
         __syncthreads();
         if (threadIdx.x == 0) {
             const float m = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
-            if (m > 0.0f && __float_as_uint(m) > __hip_atomic_load(peak_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(peak_bits, __float_as_uint(m));
+            __hip_atomic_store(slots + 1 + blockIdx.x, __float_as_uint(m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned t = __hip_atomic_fetch_add(slots, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            is_last = t == gridDim.x - 1;
+        }
+        __syncthreads();
+        if (is_last) {
+            if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            __syncthreads();
+            unsigned m = 0;
+            for (unsigned b = threadIdx.x; b < gridDim.x; b += 256) {
+                const unsigned v = __hip_atomic_load(slots + 1 + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                m = v > m ? v : m;                 // non-negative floats order like their bit patterns
+            }
+            for (int o = 32; o > 0; o >>= 1) { const unsigned v = __shfl_xor(m, o); m = v > m ? v : m; }
+            __syncthreads();
+            if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = __uint_as_float(m);
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                *peak_bits = __float_as_uint(fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3])));
+                __hip_atomic_store(slots, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
     }
 }
@@ -1295,7 +1344,7 @@ int fail(int code, const char* fmt, ...) {
         if (e_ != hipSuccess) return fail(e_ == hipErrorOutOfMemory ? SS_ENOMEM : SS_EHIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
     } while (0)
 
-enum WsSlot { WS_XS, WS_PLAN, WS_BMIN, WS_BMAX, WS_X, WS_BANK, WS_IDX, WS_W, WS_Y, WS_SCR, WS_SCR2, WS_FILT, WS_META, WS_CNT, WS_LUFS, WS_RES, WS_KWP, WS_KWT, WS_GW, WS_DPLAN, WS_DTASKS, WS_COUNT };
+enum WsSlot { WS_XS, WS_PLAN, WS_BMIN, WS_BMAX, WS_X, WS_BANK, WS_IDX, WS_W, WS_Y, WS_SCR, WS_SCR2, WS_FILT, WS_META, WS_CNT, WS_LUFS, WS_RES, WS_KWP, WS_KWT, WS_GW, WS_DPLAN, WS_DTASKS, WS_K1, WS_COUNT };
 
 struct Pinned {
     void* host = nullptr;
@@ -1747,7 +1796,8 @@ int render(int mode, const float* x, int64_t T, const float* bank, int32_t P, in
             if (g13 || g14) hipLaunchKernelGGL(k_xspec13, dim3(M + 1), dim3(NT13), 0, stream, dx, T, (const c32*)c->consts13, (c32*)c->ws[WS_XS], M,
                                                dy, (int64_t)C * T, (g13 || qgroups) ? (int*)c->ws[WS_CNT] : (int*)nullptr, g13 ? 1 : qgroups + 1,
                                                g13 ? 0 : qinit, xdiv, rs, xspec_stages_plan ? (const uint4*)pin->host : (const uint4*)nullptr,
-                                               xspec_stages_plan ? (uint4*)c->ws[WS_PLAN] : (uint4*)nullptr, xspec_stages_plan ? (int)blob16 : 0);
+                                               xspec_stages_plan ? (uint4*)c->ws[WS_PLAN] : (uint4*)nullptr, xspec_stages_plan ? (int)blob16 : 0,
+                                               dev_plan ? (const int32_t*)c->async_status : (const int32_t*)nullptr);
             if (xspec_stages_plan) {       // the ring slot may be rewritten once the spectra kernel has consumed it
                 HIPCHK(hipEventRecord(pin->ev, stream));
                 pin->pending = true;
@@ -1916,6 +1966,9 @@ int ss_async_status(int32_t* code, int64_t* where, void* stream_) {
     if (where) *where = 0;
     if (!c->async_status) return SS_OK;
     hipStream_t stream = (hipStream_t)stream_;
+    // the status word is per device: the planner that may have latched it ran on the stream of the last render -- wait for THAT stream
+    // first, or a poll through another stream could read the word before k_plan_explicit has run and miss the error
+    if (c->have_last && c->last_stream != stream) HIPCHK(hipStreamSynchronize(c->last_stream));
     int32_t h[4] = {0, 0, 0, 0};
     HIPCHK(hipMemcpyAsync(h, c->async_status, 16, hipMemcpyDeviceToHost, stream));
     HIPCHK(hipStreamSynchronize(stream));
@@ -1956,14 +2009,18 @@ static int rir_synth(const SsRirParams* p, float* bank, float* peak, uint32_t fl
     const bool dev = (flags & SS_FLAG_DEVICE_PTR) != 0;
     const size_t pc = (size_t)p->P * p->C;
     const size_t meta = pc * (sizeof(int32_t) + sizeof(float));
-    Pinned* pin;
-    if ((rc = pinned_acquire(c, meta, &pin))) return rc;
-    memcpy(pin->host, p->delay, pc * sizeof(int32_t));
-    memcpy((char*)pin->host + pc * sizeof(int32_t), p->dgain, pc * sizeof(float));
-    if ((rc = ws_ensure(c, WS_META, meta))) return rc;
-    HIPCHK(hipMemcpyAsync(c->ws[WS_META], pin->host, meta, hipMemcpyHostToDevice, stream));
-    HIPCHK(hipEventRecord(pin->ev, stream));
-    pin->pending = true;
+    const bool meta_dev = (flags & SS_FLAG_META_DEVICE) != 0;      // delay / dgain already live in HBM (a scene generator keeps its geometry there)
+    if (meta_dev && !dev) return fail(SS_EINVAL, "SS_FLAG_META_DEVICE needs SS_FLAG_DEVICE_PTR");
+    if (!meta_dev) {
+        Pinned* pin;
+        if ((rc = pinned_acquire(c, meta, &pin))) return rc;
+        memcpy(pin->host, p->delay, pc * sizeof(int32_t));
+        memcpy((char*)pin->host + pc * sizeof(int32_t), p->dgain, pc * sizeof(float));
+        if ((rc = ws_ensure(c, WS_META, meta))) return rc;
+        HIPCHK(hipMemcpyAsync(c->ws[WS_META], pin->host, meta, hipMemcpyHostToDevice, stream));
+        HIPCHK(hipEventRecord(pin->ev, stream));
+        pin->pending = true;
+    }
     const size_t bytes = sizeof(float) * pc * p->L;
     float* dbank = bank;
     if (!dev) {
@@ -1977,7 +2034,6 @@ static int rir_synth(const SsRirParams* p, float* bank, float* peak, uint32_t fl
             if ((rc = ws_ensure(c, WS_SCR, 64))) return rc;
             dpeak = (unsigned int*)c->ws[WS_SCR];
         }
-        HIPCHK(hipMemsetAsync(dpeak, 0, sizeof(unsigned int), stream));
     }
     RirDev d;
     d.P = p->P; d.C = p->C; d.L = p->L;
@@ -1985,23 +2041,34 @@ static int rir_synth(const SsRirParams* p, float* bank, float* peak, uint32_t fl
     d.srho = (float)std::sqrt(1.0 - (double)p->rho * (double)p->rho);
     d.inv_tau = 6.91 / ((double)p->rt60 * (double)p->fs);
     d.seed = p->seed;
-    d.delay = (const int32_t*)c->ws[WS_META];
-    d.dgain = (const float*)((const char*)c->ws[WS_META] + pc * sizeof(int32_t));
+    d.delay = meta_dev ? p->delay : (const int32_t*)c->ws[WS_META];
+    d.dgain = meta_dev ? p->dgain : (const float*)((const char*)c->ws[WS_META] + pc * sizeof(int32_t));
     const int64_t CL = (int64_t)p->C * p->L;
-    const bool fast32 = (uint64_t)pc * (uint64_t)p->L < ((uint64_t)1 << 32);
-    // taps per thread: the chain over the positions is sequential, so the parallelism is C * L / V threads.  Four taps per thread
-    // (16-byte stores) leave a config-2 bank (384 000 taps per position) with 1 500 waves for 1 024 SIMDs -- half of them carry two
-    // waves, the others one; two taps per thread (3 000 waves) fill them evenly: 129 -> ~100 us.  V = 4 from 4 waves per SIMD on.
+    const bool fast32 = (uint64_t)pc * (uint64_t)p->L < ((uint64_t)1 << 33);      // pair counters below 2^32
+    // taps per thread: the chain over the positions is sequential, so the parallelism is C * L / V threads.  Two taps (one Box-Muller
+    // pair, 8-byte stores) per thread: a config-2 bank (384 000 taps per position) runs 3 000 waves on the 1 024 SIMDs; four taps per
+    // thread (16-byte stores) once that still leaves 8 waves per SIMD.  An odd L takes the one-tap form.
     static const int synth_v = knob("SS_SYNTH_V") ? atoi(knob("SS_SYNTH_V")) : 0;
-    const bool big = CL / 4 / 64 >= (int64_t)c->num_cu * 16;
-    const bool vec4 = p->L % 4 == 0 && ((uintptr_t)dbank & 15) == 0 && (synth_v ? synth_v == 4 : big);
-    const bool vec2 = !vec4 && p->L % 2 == 0 && ((uintptr_t)dbank & 7) == 0 && (synth_v ? synth_v == 2 : true);
+    const bool even = p->L % 2 == 0;
+    const bool big = CL / 4 / 64 >= (int64_t)c->num_cu * 32;
+    const bool vec4 = even && p->L % 4 == 0 && ((uintptr_t)dbank & 15) == 0 && (synth_v ? synth_v == 4 : big);
+    const bool vec2 = !vec4 && even && ((uintptr_t)dbank & 7) == 0 && (synth_v ? synth_v != 1 : true);
     const dim3 grid((unsigned)((CL / (vec4 ? 4 : (vec2 ? 2 : 1)) + 255) / 256));
-    if (fast32 && vec4) hipLaunchKernelGGL((k_rir_synth<true, 4>), grid, dim3(256), 0, stream, d, dbank, dpeak);
-    else if (fast32 && vec2) hipLaunchKernelGGL((k_rir_synth<true, 2>), grid, dim3(256), 0, stream, d, dbank, dpeak);
-    else if (fast32) hipLaunchKernelGGL((k_rir_synth<true, 1>), grid, dim3(256), 0, stream, d, dbank, dpeak);
-    else if (vec4) hipLaunchKernelGGL((k_rir_synth<false, 4>), grid, dim3(256), 0, stream, d, dbank, dpeak);
-    else hipLaunchKernelGGL((k_rir_synth<false, 1>), grid, dim3(256), 0, stream, d, dbank, dpeak);
+    unsigned int* slots = nullptr;
+    if (dpeak) {       // per-workgroup maxima + the arrival ticket (word 0; the last arriver of every launch leaves it at 0 again)
+        const size_t need = sizeof(unsigned int) * ((size_t)grid.x + 1);
+        if (c->ws_cap[WS_K1] < need) {
+            if ((rc = ws_ensure(c, WS_K1, need))) return rc;
+            HIPCHK(hipMemsetAsync(c->ws[WS_K1], 0, sizeof(unsigned int), stream));
+        }
+        slots = (unsigned int*)c->ws[WS_K1];
+    }
+    if (fast32 && vec4) hipLaunchKernelGGL((k_rir_synth<true, 4>), grid, dim3(256), 0, stream, d, dbank, dpeak, slots);
+    else if (fast32 && vec2) hipLaunchKernelGGL((k_rir_synth<true, 2>), grid, dim3(256), 0, stream, d, dbank, dpeak, slots);
+    else if (fast32) hipLaunchKernelGGL((k_rir_synth<true, 1>), grid, dim3(256), 0, stream, d, dbank, dpeak, slots);
+    else if (vec4) hipLaunchKernelGGL((k_rir_synth<false, 4>), grid, dim3(256), 0, stream, d, dbank, dpeak, slots);
+    else if (vec2) hipLaunchKernelGGL((k_rir_synth<false, 2>), grid, dim3(256), 0, stream, d, dbank, dpeak, slots);
+    else hipLaunchKernelGGL((k_rir_synth<false, 1>), grid, dim3(256), 0, stream, d, dbank, dpeak, slots);
     HIPCHK(hipGetLastError());
     if (!dev) {
         HIPCHK(hipMemcpyAsync(bank, dbank, bytes, hipMemcpyDeviceToHost, stream));

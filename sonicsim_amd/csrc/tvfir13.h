@@ -341,7 +341,7 @@ SS_HD void g13_step(Env& env, const Lds13& l, const P& prm, const Task13& tk, St
 // window that starts at (m - (2^rs - 1)) * (B13 >> rs) - B13, i.e. the 2^rs - 1 windows that begin before -B13 + hop .. are kept too
 // (they still cover samples of x); rs = 0 is the block grid the other engines use.
 template <class Env> SS_HD void xspec13_body(Env& env, const float* x, int64_t T, const c32* consts, c32* Xs, int m, int M,
-                                             float* yzero, int64_t nzero, const float* xdiv = nullptr, int rs = 0) {
+                                             float* yzero, int64_t nzero, const float* xdiv = nullptr, int rs = 0, float fill = 0.0f) {
     const int tid = env.tid();
     float lo[8], hi[8];
     if (m < M) {
@@ -361,10 +361,18 @@ template <class Env> SS_HD void xspec13_body(Env& env, const float* x, int64_t T
         const int64_t chunk = (n4 + M) / (M + 1);
         const int64_t zlo = (int64_t)m * chunk, zhi = zlo + chunk < n4 ? zlo + chunk : n4;
         f4* y4 = reinterpret_cast<f4*>(yzero);
-        const f4 z{0.0f, 0.0f, 0.0f, 0.0f};
+        const f4 z{fill, fill, fill, fill};        // 0; NaN when the device planner latched an error (the output must not pass as valid silence)
+#if defined(__HIP_DEVICE_COMPILE__) && defined(SS_ZFILL_SC1)
+        // experiment: write-through stores -- 30.7 MB of zeros left DIRTY in the L2s are written back at the kernel boundary
+        // (MI355X_MICROARCH.md "boundary": + B / 6 TB/s), i.e. in front of the render kernel
+        const f4v zz = {fill, fill, fill, fill};
+        for (int64_t i = zlo + tid; i < zhi; i += NT13)
+            asm volatile("global_store_dwordx4 %0, %1, off sc1\n s_nop 1" :: "v"(y4 + i), "v"(zz) : "memory");
+#else
         for (int64_t i = zlo + tid; i < zhi; i += NT13) y4[i] = z;
+#endif
         if (m == 0)
-            for (int64_t i = n4 * 4 + tid; i < nzero; i += NT13) yzero[i] = 0.0f;
+            for (int64_t i = n4 * 4 + tid; i < nzero; i += NT13) yzero[i] = fill;
     }
     if (m >= M) return;              // (there is no zero spectrum any more: the render kernels' descriptors return zeros)
     Lds13 l; l.base = env.lds();

@@ -62,25 +62,28 @@ def _noise_types(noise_type):
 
 
 class _StemCache:
-    """Folder -> resident stems.  ``get(folder, name, mono)`` returns a float32 device tensor (T,) if mono else (C, T)."""
+    """(folder, file, mono) -> resident stem: a float32 device tensor (T,) if mono else (C, T).  Least-recently-used eviction with
+    ``limit`` entries (a hit moves the entry to the young end), i.e. at most ``limit`` stems of C * T * 4 bytes stay in HBM
+    (8 stems per cached folder: 64 folders of 8-channel 60 s stems = 15.7 GB; mono 2 GB)."""
 
     def __init__(self, device, loader, limit):
-        self.device, self.loader, self.limit = device, loader or wavio.load, limit
-        self.store: dict = {}
+        import collections
+        self.device, self.loader, self.limit = device, loader or wavio.load, max(1, int(limit))
+        self.store = collections.OrderedDict()
 
     def get(self, folder, name, mono):
         import torch
         key = (folder, name, bool(mono))
         t = self.store.get(key)
-        if t is None:
-            raw = self.store.get((folder, name, None))
-            if raw is None:
-                wav, _ = self.loader(os.path.join(folder, name))
-                raw = torch.from_numpy(np.ascontiguousarray(wav, dtype=np.float32)).to(self.device)
-            t = ops.mean_channels(raw) if mono else raw              # wav.mean(dim=0), sep :63 / :77
-            if len(self.store) >= self.limit:
-                self.store.pop(next(iter(self.store)))
-            self.store[key] = t
+        if t is not None:
+            self.store.move_to_end(key)
+            return t
+        wav, _ = self.loader(os.path.join(folder, name))
+        raw = torch.from_numpy(np.ascontiguousarray(wav, dtype=np.float32)).to(self.device)
+        t = ops.mean_channels(raw) if mono else raw              # wav.mean(dim=0), sep :63 / :77
+        while len(self.store) >= self.limit:
+            self.store.popitem(last=False)
+        self.store[key] = t
         return t
 
 
@@ -107,7 +110,11 @@ class MovingTrainDataset:
         noi = [self.cache.get(speech_dir, "{}_audio.wav".format(n), self.is_mono) for n in _noise_types(self.noise_type)]
         total = spk[0].shape[-1]
         n = int(self.sample_rate * self.duration)
-        hi = total - self.sample_rate * self.duration                                          # (a float, like the reference's bound)
+        hi = total - self.sample_rate * self.duration                                          # (a float in the reference: randint(0, float))
+        if float(hi) != int(hi):
+            raise ValueError(f"sample_rate * duration = {self.sample_rate * self.duration} is not a whole number of samples: the reference's "
+                             "random.randint(0, total - sample_rate * duration) raises ValueError for it as well")
+        hi = int(hi)         # an integral float draws the same values as the int (Python <= 3.11 accepts it with a DeprecationWarning, 3.12 raises TypeError)
         start, for_idx = 0, 0
         while for_idx <= 100:                                                                  # :84-100
             # judge up to `lookahead` future draws in one launch, then rewind the stream to just after the one that settles the loop

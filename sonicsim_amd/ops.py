@@ -245,13 +245,30 @@ def rir_bank_synth(delay, dgain, L, fs, rt60, seed, tail_gain=0.05, rho=0.9, dev
     return_peak=True -> (bank, peak): max |bank| tracked inside the generating kernel (row G's abs().max() without a second
     pass) -- a one-element device tensor (no synchronisation) or a Python float for the NumPy form."""
     lib = _lib.load()
-    delay = np.ascontiguousarray(np.asarray(delay, dtype=np.int32))
-    dgain = np.ascontiguousarray(np.asarray(dgain, dtype=np.float32))
-    if delay.ndim != 2 or delay.shape != dgain.shape:
-        raise ValueError("delay / dgain must both be (P, C)")
-    P, C = delay.shape
-    prm = _lib.SsRirParams(P, C, int(L), float(fs), float(rt60), float(tail_gain), float(rho), int(seed) & 0xFFFFFFFF,
-                           delay.ctypes.data_as(_lib.c_i32p), dgain.ctypes.data_as(_lib.c_f32p))
+    meta_dev = _is_dev(delay) and _is_dev(dgain)
+    if meta_dev:
+        # geometry already resident in HBM (int32 / float32 (P, C) tensors on the bank's device): no staging copy on the stream
+        import torch
+        if delay.dtype != torch.int32 or dgain.dtype != torch.float32 or not delay.is_contiguous() or not dgain.is_contiguous():
+            raise ValueError("device delay / dgain must be contiguous int32 / float32 tensors")
+        if delay.dim() != 2 or delay.shape != dgain.shape or delay.device != dgain.device:
+            raise ValueError("delay / dgain must both be (P, C) on one device")
+        if device is None:
+            device = delay.device
+        if torch.device(device) != delay.device:
+            raise ValueError("delay / dgain live on another device than the requested bank")
+        P, C = (int(v) for v in delay.shape)
+        prm = _lib.SsRirParams(P, C, int(L), float(fs), float(rt60), float(tail_gain), float(rho), int(seed) & 0xFFFFFFFF,
+                               ctypes.cast(ctypes.c_void_p(delay.data_ptr()), _lib.c_i32p), ctypes.cast(ctypes.c_void_p(dgain.data_ptr()), _lib.c_f32p))
+    else:
+        delay = np.ascontiguousarray(np.asarray(delay.cpu() if _is_torch(delay) else delay, dtype=np.int32))
+        dgain = np.ascontiguousarray(np.asarray(dgain.cpu() if _is_torch(dgain) else dgain, dtype=np.float32))
+        if delay.ndim != 2 or delay.shape != dgain.shape:
+            raise ValueError("delay / dgain must both be (P, C)")
+        P, C = delay.shape
+        prm = _lib.SsRirParams(P, C, int(L), float(fs), float(rt60), float(tail_gain), float(rho), int(seed) & 0xFFFFFFFF,
+                               delay.ctypes.data_as(_lib.c_i32p), dgain.ctypes.data_as(_lib.c_f32p))
+    mflag = _lib.FLAG_META_DEVICE if meta_dev else 0
     if device is None:
         bank = np.empty((P, C, int(L)), dtype=np.float32)
         if return_peak:
@@ -266,9 +283,9 @@ def rir_bank_synth(delay, dgain, L, fs, rt60, seed, tail_gain=0.05, rho=0.9, dev
     _set_device(bank)
     if return_peak:
         peak = torch.empty(1, dtype=torch.float32, device=dev)
-        _lib.check(lib.ss_rir_bank_synth_peak_f32(ctypes.byref(prm), _ptr(bank), _ptr(peak), _lib.FLAG_DEVICE_PTR, _stream_ptr(bank)))
+        _lib.check(lib.ss_rir_bank_synth_peak_f32(ctypes.byref(prm), _ptr(bank), _ptr(peak), _lib.FLAG_DEVICE_PTR | mflag, _stream_ptr(bank)))
         return bank, peak
-    _lib.check(lib.ss_rir_bank_synth_f32(ctypes.byref(prm), _ptr(bank), _lib.FLAG_DEVICE_PTR, _stream_ptr(bank)))
+    _lib.check(lib.ss_rir_bank_synth_f32(ctypes.byref(prm), _ptr(bank), _lib.FLAG_DEVICE_PTR | mflag, _stream_ptr(bank)))
     return bank
 
 

@@ -90,8 +90,8 @@ def render_sonicset_sample(inp: SceneInputs, sirs=(0.0,), snr=15.0, lufs_seed=No
 @dataclass
 class SceneSpec:
     """Host-side description of one scene + its dry signals in HBM (everything the RIR provider and the renders need)."""
-    speakers: list        # 3 x (x (T,) device, delay (P,C) i32, dgain (P,C) f32, seg_len (P-1,), rt60)
-    statics: list         # 2 x (x (T,) device, delay (1,C), dgain (1,C), rt60)
+    speakers: list        # 3 x (x (T,) device, delay (P,C) i32 device, dgain (P,C) f32 device, seg_len (P-1,) host, rt60)
+    statics: list         # 2 x (x (T,) device, delay (1,C) device, dgain (1,C) device, rt60)
     T: int
     C: int
     L: int
@@ -105,10 +105,12 @@ def make_scene_spec(device, scene=0, config="cfg2") -> SceneSpec:
     spk, st = [], []
     for s in range(3):
         sc = synth.make_scene(config, scene=scene * 8 + s)
-        spk.append((torch.from_numpy(sc.x).to(device), sc.delay, sc.dgain, synth.scene_segments(sc, scene * 8 + s), sc.rt60))
+        spk.append((torch.from_numpy(sc.x).to(device), torch.from_numpy(sc.delay).to(device), torch.from_numpy(sc.dgain).to(device),
+                    synth.scene_segments(sc, scene * 8 + s), sc.rt60))          # the provider's geometry sits in HBM next to the dry signal
     for s in range(2):
         sc = synth.make_scene(config, scene=scene * 8 + 4 + s, P=1)
-        st.append((torch.from_numpy(sc.x).to(device), sc.delay[:1], sc.dgain[:1], sc.rt60))
+        st.append((torch.from_numpy(sc.x).to(device), torch.from_numpy(sc.delay[:1].copy()).to(device), torch.from_numpy(sc.dgain[:1].copy()).to(device),
+                   sc.rt60))
     return SceneSpec(spk, st, sc.T, sc.C, sc.L, sc.fs)
 
 

@@ -94,6 +94,13 @@ def render_time_sharded(x, rirs, seg_len, rank=None, world=None, gather=True):
     if world is None:
         world = dist.get_world_size() if dist.is_initialized() else 1
         rank = dist.get_rank() if dist.is_initialized() else 0
+    elif rank is None:
+        if dist.is_initialized() and dist.get_world_size() == world:
+            rank = dist.get_rank()
+        else:
+            raise ValueError("render_time_sharded(world=k) needs rank= as well (no process group of that size to take it from)")
+    if not 0 <= rank < world:
+        raise ValueError(f"rank {rank} outside [0, {world})")
     cuts = shard_cuts(seg_len, world)
     t0, t1 = cuts[rank], cuts[rank + 1]
     C = rirs.shape[1]

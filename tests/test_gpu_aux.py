@@ -109,6 +109,23 @@ def test_rir_bank_synth_large_counter_path(gpu):
         assert peak == np.abs(got).max()
 
 
+def test_rir_bank_synth_device_metadata_and_repeated_peak(gpu):
+    """SS_FLAG_META_DEVICE: delay / dgain already in HBM give the same bank bit for bit; the peak (per-workgroup slots + arrival ticket,
+    no memset of the result word) is right on EVERY one of many back-to-back launches of different sizes"""
+    from sonicsim_amd import ops
+    rng = np.random.default_rng(8)
+    for (P, C, L) in ((5, 3, 6000), (9, 2, 40000), (4, 8, 2048), (3, 1, 777)):
+        delay = rng.integers(5, 200, (P, C)).astype(np.int32)
+        dgain = rng.uniform(0.2, 1.5, (P, C)).astype(np.float32)
+        host, hpeak = ops.rir_bank_synth(delay, dgain, L, 16000, 0.4, 99, device=gpu, return_peak=True)
+        for rep in range(4):
+            dev, dpeak = ops.rir_bank_synth(torch.from_numpy(delay).to(gpu), torch.from_numpy(dgain).to(gpu), L, 16000, 0.4, 99, return_peak=True)
+            assert torch.equal(dev, host)
+            assert float(dpeak) == float(hpeak) == float(dev.abs().max())
+    with pytest.raises(ValueError):
+        ops.rir_bank_synth(torch.from_numpy(delay).to(gpu).to(torch.int64), torch.from_numpy(dgain).to(gpu), 100, 16000, 0.4, 1)
+
+
 def test_generate_rir_combination_contract(gpu):
     from sonicsim_amd import SonicSim_audio as A, SonicSim_rir as R
     src = [list(p) for p in OR.random_walk(5, 2)]

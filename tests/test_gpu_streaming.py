@@ -65,3 +65,58 @@ def test_streaming_chunks(gpu):
     host = streaming.StreamingRenderer(bank.cpu().numpy(), seg)     # host arrays work too (staged through the library)
     yh = np.concatenate([host.push(sc.x[:30000]), host.push(sc.x[30000:])], axis=1)
     assert rel_rms(yh, full.cpu().numpy()) < 2e-6
+
+
+def _sharded_worker(rank, world, port, config, q):
+    """one of `world` processes that share cuda:0 over gloo (RCCL refuses two ranks on one device): its time slice of ONE render"""
+    import os
+    import sys
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import torch.distributed as dist
+    from sonicsim_amd import ops, parallel, streaming, synth
+    parallel.init_process_group(backend="gloo")
+    gpu = torch.device("cuda", 0)
+    sc = synth.make_scene(config, scene=2)
+    seg = synth.scene_segments(sc, 2)
+    bank, peak = ops.rir_bank_synth(sc.delay, sc.dgain, sc.L, sc.fs, sc.rt60, sc.bank_seed, device=gpu, return_peak=True)
+    ops.divide_by_(bank, peak)
+    x = torch.from_numpy(sc.x).to(gpu)
+    y = streaming.render_time_sharded(x, bank, seg, gather=True)            # rank / world from the process group
+    cuts = streaming.shard_cuts(seg, world)
+    if rank == 0:
+        full = ops.convolve_moving_seg(x, bank, seg)
+        torch.cuda.synchronize()
+        assert y.shape == full.shape
+        num = float((y.double() - full.double()).pow(2).mean().sqrt())
+        den = float(full.double().pow(2).mean().sqrt())
+        q.put(("ok", num / den, tuple(y.shape), cuts))
+    else:
+        assert y is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("config", ["tiny", "cfg5"])
+def test_time_sharded_render_on_two_ranks(gpu, config):
+    """SURVEY 8e "finer-grained option" at the size it exists for: ONE config-5 render (120 s @ 48 kHz, 500 points, 96000 taps) cut
+    into two time shards on segment boundaries, rendered by two processes (gloo; they share this box's one GPU), gathered to rank 0
+    (`gather=True`) and compared with the one-piece render: float32 round-off (the block grid is anchored at each shard's start)."""
+    import socket
+    import torch.multiprocessing as mp
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_sharded_worker, args=(r, 2, port, config, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=300)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    tag, rel, shape, cuts = q.get(timeout=10)
+    assert tag == "ok" and rel < 2e-6, rel
+    assert cuts[0] == 0 and cuts[-1] == shape[1] and 0.3 * shape[1] < cuts[1] < 0.7 * shape[1]
+    print(f"{config}: two time shards {cuts} vs one piece: rel RMS {rel:.2e}")
