@@ -43,6 +43,7 @@ extern "C" {
 #define SS_FLAG_GEOM_ASM 0x400u   /* overlap-save engine: force the hand-scheduled gfx950 assembly kernel (segment / fixed schedules) */
 #define SS_FLAG_LAYOUT_TC 0x100u  /* audio is [T][C] instead of [C][T] (loudness / mix calls) */
 #define SS_FLAG_META_DEVICE 0x1000u /* ss_rir_bank_synth*_f32 with SS_FLAG_DEVICE_PTR: SsRirParams.delay / .dgain are DEVICE pointers (no staging copy) */
+#define SS_FLAG_RESULT_DEVICE 0x2000u /* ss_lufs_norm_batch_f32 with SS_FLAG_DEVICE_PTR: `result` is a DEVICE array of 4 * S doubles; the call only enqueues work (no synchronisation) */
 #define SS_FLAG_ASYNC_PLAN 0x800u /* ss_convolve_moving_f32 with device pointers: plan the explicit schedule on the device (no host synchronisation) */
 
 int ss_version(void);
@@ -101,6 +102,18 @@ int ss_convolve_moving_seg_f32(const float* x, int64_t T, const float* rirs, int
  * round-off only (1e-7 relative). */
 int ss_convolve_moving_seg_div_f32(const float* x, int64_t T, const float* rirs, int32_t P, int32_t C, int32_t L,
                                    const int64_t* seg_len, const float* divisor, float* y, uint32_t flags, void* stream);
+
+/* ---- a whole scene in ONE persistent launch (round 3).  SonicSet.py:61-94 renders three moving speakers (interpolate_moving_audio,
+ * SonicSim_moving.py:98-125) and two static sources (convolve_fixed_receiver, :47-61) of the same length one after the other; here the
+ * `nsrc` (1..8) renders share one spectra launch and one render launch (the tasks of all sources in one XCD-aware list), which saves a
+ * spectra launch, two kernel boundaries and a load-balancing tail per extra source.  Source s: dry signal x[s][T], filters rirs[s]
+ * [P[s]][C][L] (P[s] == 1: a static source, its one filter applied with coefficient 1; P[s] >= 2: a moving source with HOST segment
+ * lengths seg_len[s][P[s]-1], sum = T, as in ss_convolve_moving_seg_f32), optional device scalar divisor[s] (deferred peak
+ * normalisation as in ss_convolve_moving_seg_div_f32; the array or an entry may be NULL), output y[s][C][T].  The pointer ARRAYS are host
+ * arrays of DEVICE pointers (SS_FLAG_DEVICE_PTR required); C < 65536, L > 4096, T < 2^30 (the assembly engine's shapes).  Results are
+ * bit-identical to the separate calls. */
+int ss_convolve_scene_f32(int32_t nsrc, const float* const* x, int64_t T, const float* const* rirs, const int32_t* P, int32_t C, int32_t L,
+                          const int64_t* const* seg_len, const float* const* divisor, float* const* y, uint32_t flags, void* stream);
 
 /* ---- row F: SonicSim_moving.py:47-61  convolve_fixed_receiver --------------------------------
  * y[c,t] = (x * h[c])[t], 0 <= t < T.   h[C][L]. Replaces scipy.signal.fftconvolve(...)[:, :T]. */

@@ -182,16 +182,22 @@ def lufs_norm(data, sr, norm=-6, allow_many_channels: bool = False, channel_firs
     return norm_data, gain
 
 
-def get_lufs_norm_audio_batch(stems, sr=16000, lufs=(-6,), allow_many_channels: bool = False):
+def get_lufs_norm_audio_batch(stems, sr=16000, lufs=(-6,), allow_many_channels: bool = False, sync: bool = True):
     """Extension: ``get_lufs_norm_audio`` for a stack of stems (S, C, T) in ONE device call.  The class loudness of stem i
     is drawn from the global NumPy RNG in stem order, exactly as S successive reference calls (:83-86) would draw them.
-    Returns (normalised stack (S, C, T), [gain_0, ...])."""
+    Returns (normalised stack (S, C, T), [gain_0, ...]).  sync=False (device stacks): the call only enqueues work and the gains come
+    back as a float64 device tensor (S,) -- sum(out) / sum(in) like the reference's returned gain, 0 where sum(in) is 0 -- for a
+    generator that keeps rendering the next scene instead of waiting for this one's numbers (no "loudness is inf" print then)."""
     S, C, T = stems.shape
     if len(lufs) != S:
         raise ValueError("one nominal loudness per stem")
     targets = [np.random.uniform(l - 2, l + 2) for l in lufs]
     block_size = 0.4 if T / sr >= 0.4 else T / sr
     _, lo, hi, weights, _ = _meter_args(stems[0], sr, block_size, allow_many_channels, True)
+    if not sync:
+        import torch
+        out, res = ops.lufs_norm(stems, _kw_coef(float(sr)), lo, hi, block_size * sr, weights, targets, layout_tc=False, result_device=True)
+        return out, torch.where(res[:, 3] != 0, res[:, 2] / res[:, 3], torch.zeros_like(res[:, 2]))
     out, loud, _lin, n, d = ops.lufs_norm(stems, _kw_coef(float(sr)), lo, hi, block_size * sr, weights, targets, layout_tc=False)
     for l in loud:
         if math.isinf(l):

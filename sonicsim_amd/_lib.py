@@ -22,6 +22,7 @@ FLAG_GEOM_13 = 0x200
 FLAG_GEOM_ASM = 0x400
 FLAG_ASYNC_PLAN = 0x800
 FLAG_META_DEVICE = 0x1000
+FLAG_RESULT_DEVICE = 0x2000
 
 SS_EINVAL, SS_EHIP, SS_ENOMEM, SS_ENODEV = -1, -2, -3, -4
 
@@ -60,6 +61,8 @@ _SIGS = {
     "ss_convolve_moving_seg_div_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32,
                                                       ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32,
                                                       ctypes.c_void_p]),
+    "ss_convolve_scene_f32": (ctypes.c_int, [ctypes.c_int32, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32,
+                                             ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p]),
     "ss_rms_db_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, c_f64p, ctypes.c_uint32, ctypes.c_void_p]),
     "ss_mix_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, c_f32p,
                                   ctypes.c_float, ctypes.c_void_p, c_f32p, ctypes.c_uint32, ctypes.c_void_p]),
@@ -84,7 +87,7 @@ _SIGS = {
                                         ctypes.c_int32, ctypes.c_double, c_f64p, ctypes.c_double, c_f64p, ctypes.c_uint32,
                                         ctypes.c_void_p]),
     "ss_lufs_norm_batch_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, c_f64p,
-                                              c_i64p, c_i64p, ctypes.c_int32, ctypes.c_double, c_f64p, c_f64p, c_f64p, ctypes.c_uint32,
+                                              c_i64p, c_i64p, ctypes.c_int32, ctypes.c_double, c_f64p, c_f64p, ctypes.c_void_p, ctypes.c_uint32,
                                               ctypes.c_void_p]),
     "ss_prof_enable": (ctypes.c_int, [ctypes.c_int]),
     "ss_prof_read": (ctypes.c_int, [ctypes.c_int, c_i64p, c_f64p]),

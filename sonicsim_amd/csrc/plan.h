@@ -313,6 +313,85 @@ inline void plan_seg_lpt(const std::vector<int64_t>& seg_start /*[P], last == T*
     }
 }
 
+// One task list for SEVERAL sources rendered by one persistent launch (a SonicSet scene: 3 moving + 2 static renders).  Task.chan carries
+// the source in its upper half (source << 16 | channel: the assembly kernel looks the source's bank / spectra / output / segment table up
+// in its argument table).  Per source the rows are cut into `groups` time ranges of equal cost exactly as in plan_seg_lpt (a static source,
+// P == 1, is one row over every block: its ranges are stretches of blocks); queue g = the g-th range of source 0, then of source 1, ...
+// (an XCD works through one source's stretch at a time, so its L2 holds one stretch of input spectra), every (source, range) in descending
+// cost.  Output layout = plan_seg_lpt's two-level form: the first m tasks of every queue interleaved (position k * groups + g), the rest --
+// the smallest tail_pct % -- in ONE shared queue behind them, descending cost; *main_out = m * groups.
+struct SceneSrc {
+    const int64_t* seg_start;   // [P] (last == T) for a moving source; ignored for P == 1
+    int P;
+};
+inline void plan_scene_lpt(const SceneSrc* src, int nsrc, int64_t T, int C, int block, int jmax, int NP, std::vector<Task>& out, int groups,
+                           int tail_pct, int32_t* main_out) {
+    auto cost = [NP](int j0, int nj) { return std::min(NP, j0 + nj) * (10 + 2 * nj) + 12 * nj; };
+    static thread_local std::vector<std::vector<Task>> q;
+    static thread_local std::vector<Task> part;
+    if (groups < 1) groups = 1;
+    if (groups > 64) groups = 64;
+    q.resize((size_t)groups);
+    for (auto& v : q) v.clear();
+    const int64_t nblk = (T + block - 1) / block;
+    for (int s = 0; s < nsrc; ++s) {
+        // (row, first block, blocks) of this source in time order + its total cost
+        struct RT { int32_t row, j0, nj, c; };
+        static thread_local std::vector<RT> rt;
+        rt.clear();
+        int64_t total = 0;
+        if (src[s].P <= 1) {
+            for (int64_t j = 0; j < nblk; j += jmax) {
+                const int nj = (int)std::min<int64_t>(jmax, nblk - j);
+                rt.push_back(RT{0, (int32_t)j, nj, cost((int)j, nj)});
+                total += rt.back().c;
+            }
+        } else {
+            const int P = src[s].P;
+            const int64_t* ss = src[s].seg_start;
+            for (int r = 0; r < P; ++r) {
+                const int64_t a0 = ss[r > 0 ? r - 1 : r], a2 = ss[r < P - 1 ? r + 1 : r];
+                row_tasks(a0, a2, block, jmax, 0, [&](int j, int nj) { rt.push_back(RT{r, j, nj, cost(j, nj)}); total += rt.back().c; });
+            }
+        }
+        // ranges of equal cost (whole rows stay together like in plan_seg_lpt: the range of a row is that of its cost midpoint)
+        int64_t acc = 0;
+        size_t i = 0;
+        while (i < rt.size()) {
+            size_t e = i;
+            int64_t rc = 0;
+            while (e < rt.size() && (src[s].P > 1 ? rt[e].row == rt[i].row : e == i)) rc += rt[e++].c;
+            int g = total > 0 ? (int)((__int128)(acc + rc / 2) * groups / total) : 0;
+            if (g >= groups) g = groups - 1;
+            part.clear();
+            for (size_t k = i; k < e; ++k)
+                for (int c = 0; c < C; ++c) part.push_back(Task{rt[k].row, (int32_t)((s << 16) | c), rt[k].j0, rt[k].nj});
+            q[(size_t)g].insert(q[(size_t)g].end(), part.begin(), part.end());
+            acc += rc;
+            i = e;
+        }
+        // descending cost inside this source's share of every queue (stable: time order inside a cost class)
+        for (int g = 0; g < groups; ++g) {
+            auto& v = q[(size_t)g];
+            auto first = std::find_if(v.begin(), v.end(), [s](const Task& t) { return (t.chan >> 16) == s; });
+            std::stable_sort(first, v.end(), [&](const Task& a, const Task& b) { return cost(a.j0, a.nj) > cost(b.j0, b.nj); });
+        }
+    }
+    size_t total_n = 0, m = (size_t)-1;
+    for (const auto& v : q) { total_n += v.size(); m = std::min(m, v.size()); }
+    if (groups == 1) tail_pct = 0;
+    m = m * (size_t)(100 - (tail_pct > 0 && tail_pct < 100 ? tail_pct : 0)) / 100;
+    out.resize(total_n);
+    for (size_t k = 0; k < m; ++k)
+        for (int g = 0; g < groups; ++g) out[k * (size_t)groups + (size_t)g] = q[(size_t)g][k];
+    size_t w = m * (size_t)groups;
+    for (int g = 0; g < groups; ++g)
+        for (size_t k = m; k < q[(size_t)g].size(); ++k) out[w++] = q[(size_t)g][k];
+    std::stable_sort(out.begin() + (std::ptrdiff_t)(m * (size_t)groups), out.end(),
+                     [&](const Task& a, const Task& b) { return cost(a.j0, a.nj) > cost(b.j0, b.nj); });
+    if (main_out) *main_out = (int32_t)(m * (size_t)groups);
+}
+
 // fixed receiver: one row, every block, store pass only
 inline void build_plan_fixed(int64_t T, int C, int block, int jmax, Plan& plan) {
     plan.tasks[0].clear();

@@ -104,6 +104,32 @@ __global__ __launch_bounds__(512, 2) void k_xspec13(const float* __restrict__ x,
         for (int i = pi + (int)gridDim.x * 512; i < plan_n16; i += (int)gridDim.x * 512) plan_dst[i] = plan_src[i];
 }
 
+// the same for the sources of ONE scene launch (ss_convolve_scene_f32): blockIdx.y = source; every source has its own dry signal,
+// divisor (deferred peak normalisation, may be null), spectra array and output (zero fill)
+struct XspecSrcTab {
+    const float* x[8];
+    const float* xdiv[8];
+    c32* Xs[8];
+    float* y[8];
+};
+__global__ __launch_bounds__(512, 2) void k_xspec13_multi(XspecSrcTab tab, int64_t T, const c32* __restrict__ consts, int M, int64_t nzero,
+                                                          int* __restrict__ counter, int ncnt, int cnt_init, const uint4* __restrict__ plan_src,
+                                                          uint4* __restrict__ plan_dst, int plan_n16) {
+    __shared__ __attribute__((aligned(16))) c32 smem[LDS13_C32];
+    DevEnv env{smem};
+    const int s = (int)blockIdx.y;
+    const int bid = (int)(blockIdx.y * gridDim.x + blockIdx.x), nblk = (int)(gridDim.x * gridDim.y);
+    if (counter && bid == 0 && (int)threadIdx.x < ncnt) counter[16 * threadIdx.x] = cnt_init;
+    uint4 pv = make_uint4(0, 0, 0, 0);
+    const int pi = 4 * (bid + nblk * ((int)threadIdx.x >> 2)) + ((int)threadIdx.x & 3);      // plan staging: see k_xspec13
+    const bool pok = plan_src && pi < plan_n16;
+    if (pok) pv = plan_src[pi];
+    xspec13_body(env, tab.x[s], T, consts, tab.Xs[s], (int)blockIdx.x, M, tab.y[s], nzero, tab.xdiv[s], 0, 0.0f);
+    if (pok) plan_dst[pi] = pv;
+    if (plan_src)
+        for (int i = pi + nblk * 512; i < plan_n16; i += nblk * 512) plan_dst[i] = plan_src[i];
+}
+
 // geometry 13 (tvfir13.h): software-pipelined FFT/MAC, one barrier per transform, buffer addressing, dynamic task queue
 __global__ __launch_bounds__(512, 2) void k_os13(Params13 prm) {
     __shared__ __attribute__((aligned(16))) c32 smem[LDS13_C32];
@@ -576,6 +602,24 @@ __device__ unsigned long long g_dbg_clk[8][2][256];
 #else
 #define DBG_CLK(kid, which) do {} while (0)
 #endif
+// SS_FLAG_RESULT_DEVICE: {loudness, gain, sum(out), sum(in)} of stem g straight into a caller's device array -- the final additions in
+// k_final_sum's association (64 strided lanes, then a butterfly), so host-finished and device-finished sums are the same bits
+__global__ __launch_bounds__(64) void k_lufs_result(const double* __restrict__ res, const double* __restrict__ part, int nb, double* __restrict__ out) {
+    const int g = blockIdx.x;
+    double s0 = 0.0, s1 = 0.0;
+    for (int i = threadIdx.x; i < nb; i += 64) {
+        s0 += part[((int64_t)2 * g + 0) * nb + i];
+        s1 += part[((int64_t)2 * g + 1) * nb + i];
+    }
+    for (int o = 32; o > 0; o >>= 1) { s0 += __shfl_down(s0, o); s1 += __shfl_down(s1, o); }
+    if (threadIdx.x == 0) {
+        out[4 * g + 0] = res[4 * g + 0];
+        out[4 * g + 1] = res[4 * g + 1];
+        out[4 * g + 2] = s0;
+        out[4 * g + 3] = s1;
+    }
+}
+
 __global__ __launch_bounds__(64) void k_final_sum(const double* __restrict__ partial, int nb, double* __restrict__ out) {
     DBG_CLK(3, 0);
     double s = 0.0;
@@ -1542,8 +1586,21 @@ struct Os13AsmArgs {
     const void* w;
     int32_t qgroups;       // dynamic task queues: 0 = static stride-nwg assignment, G = workgroup b pulls from queue b % G (counter[16 * g])
     int32_t rs;            // input spectra every 4096 >> rs samples; Task::j0 in those hop units (plan.h row_tasks)
+    // ---- multi-source launches (tools/gen_asm/os13.py: ARG_NSRC, SRC_TAB): Task.chan = source << 16 | channel
+    int32_t nsrc;          // <= 1: the fields above describe the one source
+    int32_t pad0[31];
+    struct Src {
+        const void* bank;
+        const void* Xs;
+        const void* seg_start;
+        const void* inv_seg;
+        void* y;
+        int32_t P, C, mode, nwg;
+        int32_t pad[2];
+    } src[8];
 };
-static_assert(sizeof(Os13AsmArgs) == 128, "Os13AsmArgs layout");
+static_assert(sizeof(Os13AsmArgs) == 768 && offsetof(Os13AsmArgs, nsrc) == 128 && offsetof(Os13AsmArgs, src) == 256 && sizeof(Os13AsmArgs::Src) == 64,
+              "Os13AsmArgs layout");
 
 // The code object sits next to this shared library (built by sonicsim_amd/build.py); a missing file is an error
 // for the callers that asked for the assembly engine, never a silent fallback.
@@ -1794,7 +1851,8 @@ int render(int mode, const float* x, int64_t T, const float* bank, int32_t P, in
                 qinit = 0;                                   // every task, the first one included, comes from the queue
             }
             if (g13 || g14) hipLaunchKernelGGL(k_xspec13, dim3(M + 1), dim3(NT13), 0, stream, dx, T, (const c32*)c->consts13, (c32*)c->ws[WS_XS], M,
-                                               dy, (int64_t)C * T, (g13 || qgroups) ? (int*)c->ws[WS_CNT] : (int*)nullptr, g13 ? 1 : qgroups + 1,
+                                               knob("SS_NO_ZFILL") ? (float*)nullptr : dy /* (tuning build: spectra kernel without its zero fill -- results WRONG) */,
+                                               (int64_t)C * T, (g13 || qgroups) ? (int*)c->ws[WS_CNT] : (int*)nullptr, g13 ? 1 : qgroups + 1,
                                                g13 ? 0 : qinit, xdiv, rs, xspec_stages_plan ? (const uint4*)pin->host : (const uint4*)nullptr,
                                                xspec_stages_plan ? (uint4*)c->ws[WS_PLAN] : (uint4*)nullptr, xspec_stages_plan ? (int)blob16 : 0,
                                                dev_plan ? (const int32_t*)c->async_status : (const int32_t*)nullptr);
@@ -1820,6 +1878,7 @@ int render(int mode, const float* x, int64_t T, const float* bank, int32_t P, in
         ProfScope ps(c, stream, use_os ? 0 : 2);
         if (g14) {
             Os13AsmArgs a;
+            memset(&a, 0, sizeof(a));
             a.bank = dbank; a.Xs = prm.Xs; a.tasks = prm.tasks;
             a.seg_start = plan_base;
             a.inv_seg = plan_base + sizeof(int64_t) * (size_t)P;
@@ -1884,6 +1943,127 @@ int render(int mode, const float* x, int64_t T, const float* bank, int32_t P, in
     if (!dev) {
         HIPCHK(hipMemcpyAsync(y, dy, sizeof(float) * (size_t)C * T, hipMemcpyDeviceToHost, stream));
         HIPCHK(hipStreamSynchronize(stream));
+    }
+    return SS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// ONE persistent launch for all the renders of a scene (SonicSet.py:61-94: three moving speakers + two static sources): one spectra
+// launch (grid = spectra x sources), one task list over all sources (plan_scene_lpt), one k_os13_asm launch whose tasks look their
+// source up in the argument table.  Saves, per extra source, a spectra launch, two kernel boundaries and an LPT tail.
+int render_scene(int nsrc, const float* const* xs, int64_t T, const float* const* banks, const int32_t* Ps, int32_t C, int32_t L,
+                 const int64_t* const* seg_lens, const float* const* divisors, float* const* ys, uint32_t flags, void* stream_) {
+    if (nsrc < 1 || nsrc > 8) return fail(SS_EINVAL, "a scene launch takes 1..8 sources (got %d)", nsrc);
+    if (!(flags & SS_FLAG_DEVICE_PTR)) return fail(SS_EINVAL, "the scene launch takes device pointers (SS_FLAG_DEVICE_PTR)");
+    if (T < 1 || C < 1 || C > 65535 || L < 1) return fail(SS_EINVAL, "bad shape: T=%lld C=%d L=%d", (long long)T, C, L);
+    if (!(T < ((int64_t)1 << 30) && (int64_t)L * 4 < ((int64_t)1 << 31) && L > 2 * B))
+        return fail(SS_EINVAL, "the scene launch exists for the assembly engine's shapes (L > %d, T < 2^30): T=%lld L=%d", 2 * B, (long long)T, L);
+    if (!xs || !banks || !Ps || !ys) return fail(SS_EINVAL, "NULL argument");
+    for (int s = 0; s < nsrc; ++s) {
+        if (!xs[s] || !banks[s] || !ys[s] || Ps[s] < 1) return fail(SS_EINVAL, "source %d: NULL pointer or P < 1", s);
+        if (Ps[s] > 1 && (!seg_lens || !seg_lens[s])) return fail(SS_EINVAL, "source %d: a moving source (P = %d) needs its segment lengths", s, Ps[s]);
+    }
+    Ctx* c;
+    int rc = get_ctx(&c);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(c->mu);
+    hipStream_t stream = (hipStream_t)stream_;
+    if ((rc = stream_enter(c, stream))) return rc;
+    if ((rc = load_mod13(c, c->dynq))) return rc;
+    const int M = (int)((T + B12 - 1) / B12);
+    const int NPart = (L + B12 - 1) / B12;
+    // ---- segment tables (host) + task list
+    static thread_local std::vector<std::vector<int64_t>> segs;
+    segs.resize((size_t)nsrc);
+    SceneSrc ssrc[8];
+    size_t seg_off[8], seg_total = 0;
+    for (int s = 0; s < nsrc; ++s) {
+        const int P = Ps[s];
+        auto& st = segs[(size_t)s];
+        st.assign((size_t)P, 0);
+        if (P > 1) {
+            int64_t acc = 0;
+            for (int k = 0; k < P - 1; ++k) {
+                if (seg_lens[s][k] < 0) return fail(SS_EINVAL, "source %d: seg_len[%d] = %lld is negative", s, k, (long long)seg_lens[s][k]);
+                st[(size_t)k] = acc;
+                acc += seg_lens[s][k];
+            }
+            st[(size_t)P - 1] = acc;
+            if (acc != T) return fail(SS_EINVAL, "source %d: sum(seg_len) = %lld != T = %lld", s, (long long)acc, (long long)T);
+        }
+        ssrc[s].seg_start = st.data();
+        ssrc[s].P = P;
+        seg_off[s] = seg_total;
+        seg_total += 2 * sizeof(int64_t) * (size_t)P;
+    }
+    int32_t qmain = 0;
+    static const int plan_tail = knob("SS_PLAN_TAIL") ? atoi(knob("SS_PLAN_TAIL")) : 12;
+    plan_scene_lpt(ssrc, nsrc, T, C, B12, JMAX12, NPart, c->plan.tasks[0], 8, c->dynq ? plan_tail : 0, &qmain);
+    c->plan.tasks[1].clear();
+    const size_t n0 = c->plan.tasks[0].size();
+    const size_t blob = seg_total + sizeof(Task) * n0, blob16 = (blob + 15) / 16;
+    Pinned* pin;
+    if ((rc = pinned_acquire(c, blob16 * 16, &pin))) return rc;
+    memset(pin->host, 0, seg_total);
+    for (int s = 0; s < nsrc; ++s) {
+        const int P = Ps[s];
+        char* base = (char*)pin->host + seg_off[s];
+        memcpy(base, segs[(size_t)s].data(), sizeof(int64_t) * (size_t)P);
+        double* inv = reinterpret_cast<double*>(base + sizeof(int64_t) * (size_t)P);
+        for (int k = 0; k + 1 < P; ++k) {
+            const int64_t n = segs[(size_t)s][(size_t)k + 1] - segs[(size_t)s][(size_t)k];
+            inv[k] = n > 0 ? 1.0 / (double)n : 0.0;
+        }
+    }
+    memcpy((char*)pin->host + seg_total, c->plan.tasks[0].data(), sizeof(Task) * n0);
+    if ((rc = ws_ensure(c, WS_PLAN, blob16 * 16))) return rc;
+    const char* plan_base = (const char*)c->ws[WS_PLAN];
+    const size_t xs_one = sizeof(c32) * (size_t)(M + 1) * B12;
+    if ((rc = ws_ensure(c, WS_XS, xs_one * (size_t)nsrc))) return rc;
+    if ((rc = ws_ensure(c, WS_CNT, 16 * 64))) return rc;
+    const int nwg = (int)(n0 > (size_t)c->num_cu ? (size_t)c->num_cu : n0);
+    const int qgroups = !c->dynq ? 0 : ((nwg >= 8 && nwg % 8 == 0) ? 8 : 1);
+    {
+        ProfScope ps(c, stream, 1);
+        XspecSrcTab tab;
+        memset(&tab, 0, sizeof(tab));
+        for (int s = 0; s < nsrc; ++s) {
+            tab.x[s] = xs[s];
+            tab.xdiv[s] = divisors ? divisors[s] : nullptr;
+            tab.Xs[s] = (c32*)((char*)c->ws[WS_XS] + xs_one * (size_t)s);
+            tab.y[s] = ys[s];
+        }
+        hipLaunchKernelGGL(k_xspec13_multi, dim3(M + 1, nsrc), dim3(NT13), 0, stream, tab, T, (const c32*)c->consts13, M, (int64_t)C * T,
+                           qgroups ? (int*)c->ws[WS_CNT] : (int*)nullptr, qgroups + 1, 0, (const uint4*)pin->host, (uint4*)c->ws[WS_PLAN], (int)blob16);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(pin->ev, stream));
+        pin->pending = true;
+    }
+    if (!n0) return SS_OK;
+    {
+        ProfScope ps(c, stream, 0);
+        Os13AsmArgs a;
+        memset(&a, 0, sizeof(a));
+        for (int s = 0; s < nsrc; ++s) {
+            Os13AsmArgs::Src& e = a.src[s];
+            e.bank = banks[s];
+            e.Xs = (const char*)c->ws[WS_XS] + xs_one * (size_t)s;
+            e.seg_start = plan_base + seg_off[s];
+            e.inv_seg = plan_base + seg_off[s] + sizeof(int64_t) * (size_t)Ps[s];
+            e.y = ys[s];
+            e.P = Ps[s]; e.C = C; e.mode = Ps[s] > 1 ? COEF_SEG : COEF_FIXED; e.nwg = nwg;
+        }
+        a.bank = a.src[0].bank; a.Xs = a.src[0].Xs; a.seg_start = a.src[0].seg_start; a.inv_seg = a.src[0].inv_seg; a.y = a.src[0].y;
+        a.P = a.src[0].P; a.mode = a.src[0].mode;
+        a.tasks = plan_base + seg_total;
+        a.T = T; a.C = C; a.L = L; a.NP = NPart; a.M = M; a.ntasks = (int32_t)n0; a.nwg = nwg;
+        a.consts = c->consts14; a.counter = qgroups ? c->ws[WS_CNT] : nullptr;
+        a.qgroups = qgroups;
+        a.rs = (qgroups == 8 && qmain > 0 && qmain < (1 << 22) && (size_t)qmain < n0) ? qmain << 8 : 0;
+        a.nsrc = nsrc;
+        size_t asz = sizeof(a);
+        void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &asz, HIP_LAUNCH_PARAM_END};
+        HIPCHK(hipModuleLaunchKernel(c->dynq ? c->fn13q : c->fn13, (unsigned)nwg, 1, 1, NT13, 1, 1, 0, stream, nullptr, cfg));
     }
     return SS_OK;
 }
@@ -1981,6 +2161,11 @@ int ss_async_status(int32_t* code, int64_t* where, void* stream_) {
 int ss_convolve_moving_seg_f32(const float* x, int64_t T, const float* rirs, int32_t P, int32_t C, int32_t L,
                                const int64_t* seg_len, float* y, uint32_t flags, void* stream) {
     return render(COEF_SEG, x, T, rirs, P, C, L, seg_len, nullptr, nullptr, y, flags, stream);
+}
+
+int ss_convolve_scene_f32(int32_t nsrc, const float* const* x, int64_t T, const float* const* rirs, const int32_t* P, int32_t C, int32_t L,
+                          const int64_t* const* seg_len, const float* const* divisor, float* const* y, uint32_t flags, void* stream) {
+    return render_scene(nsrc, x, T, rirs, P, C, L, seg_len, divisor, y, flags, stream);
 }
 
 int ss_convolve_moving_seg_div_f32(const float* x, int64_t T, const float* rirs, int32_t P, int32_t C, int32_t L,
@@ -2470,6 +2655,12 @@ int ss_lufs_norm_batch_f32(const float* audio, float* out, int64_t T, int32_t C,
     double* part = res + 4 * (size_t)S;
     hipLaunchKernelGGL(k_scale_sums, dim3(nb, S), dim3(256), 0, stream, (const float*)da, dout, ng, 0.f, (const double*)(res + 1), part);
     HIPCHK(hipGetLastError());
+    if (flags & SS_FLAG_RESULT_DEVICE) {      // no host synchronisation: the four numbers per stem land in the caller's device array
+        if (!dev) return fail(SS_EINVAL, "SS_FLAG_RESULT_DEVICE needs SS_FLAG_DEVICE_PTR");
+        hipLaunchKernelGGL(k_lufs_result, dim3(S), dim3(64), 0, stream, (const double*)res, (const double*)part, nb, result);
+        HIPCHK(hipGetLastError());
+        return SS_OK;
+    }
     // {loudness, gain} + the partial sums of every stem come back in one go; the last (fixed-order) additions are done here
     Pinned* pin;
     if ((rc = pinned_acquire(c, sizeof(double) * res_doubles, &pin))) return rc;

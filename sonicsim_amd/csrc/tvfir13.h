@@ -362,15 +362,7 @@ template <class Env> SS_HD void xspec13_body(Env& env, const float* x, int64_t T
         const int64_t zlo = (int64_t)m * chunk, zhi = zlo + chunk < n4 ? zlo + chunk : n4;
         f4* y4 = reinterpret_cast<f4*>(yzero);
         const f4 z{fill, fill, fill, fill};        // 0; NaN when the device planner latched an error (the output must not pass as valid silence)
-#if defined(__HIP_DEVICE_COMPILE__) && defined(SS_ZFILL_SC1)
-        // experiment: write-through stores -- 30.7 MB of zeros left DIRTY in the L2s are written back at the kernel boundary
-        // (MI355X_MICROARCH.md "boundary": + B / 6 TB/s), i.e. in front of the render kernel
-        const f4v zz = {fill, fill, fill, fill};
-        for (int64_t i = zlo + tid; i < zhi; i += NT13)
-            asm volatile("global_store_dwordx4 %0, %1, off sc1\n s_nop 1" :: "v"(y4 + i), "v"(zz) : "memory");
-#else
-        for (int64_t i = zlo + tid; i < zhi; i += NT13) y4[i] = z;
-#endif
+        for (int64_t i = zlo + tid; i < zhi; i += NT13) y4[i] = z;        // (write-through `sc1` stores instead: measured, no gain -- profiles/r03i)
         if (m == 0)
             for (int64_t i = n4 * 4 + tid; i < nzero; i += NT13) yzero[i] = fill;
     }

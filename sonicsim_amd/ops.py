@@ -120,6 +120,20 @@ def convolve_moving(x, rirs, idx, w, path=None, out=None, validate=True):
         T = x.shape[0]
         _set_device(x)
         y = _out_ct(out, C, T, dev)
+        asm_engine = path in (None, "auto", "asm", "os")      # engines that may have the device planner (the library ignores the flag otherwise)
+        if validate and asm_engine:
+            # validating AND fast (round 3): plan + render optimistically on the device, then ONE synchronisation that brings back the
+            # planner's status word.  The reference raises at the call for an out-of-range index (NumPy fancy indexing,
+            # SonicSim_moving.py:89-90) and so does this; what changes is that no bounds array travels to the host and no host planner
+            # sits between the kernels (0.30 -> 0.24 ms per config-2 render).  A schedule too irregular for the device planner's task
+            # buffer falls through to the host-planned path below.
+            _lib.check(lib.ss_convolve_moving_f32(_ptr(x), T, _ptr(rirs), P, C, L, _ptr(idx), _ptr(w), _ptr(y),
+                                                  flags | _lib.FLAG_DEVICE_PTR | _lib.FLAG_ASYNC_PLAN, _stream_ptr(x)))
+            code, where = async_status(x)
+            if code == 0:
+                return y
+            if code == 1:
+                raise ValueError(f"interp_index out of range [0, {P - 2}] near sample {where} (the output buffer holds no valid render)")
         _lib.check(lib.ss_convolve_moving_f32(_ptr(x), T, _ptr(rirs), P, C, L, _ptr(idx), _ptr(w), _ptr(y),
                                               flags | _lib.FLAG_DEVICE_PTR | (0 if validate else _lib.FLAG_ASYNC_PLAN), _stream_ptr(x)))
         return y
@@ -208,6 +222,60 @@ def convolve_moving_seg(x, rirs, seg_len, path=None, out=None, bank_peak=None):
     y = np.empty((C, T), dtype=np.float32)
     _lib.check(lib.ss_convolve_moving_seg_f32(_ptr(x), T, _ptr(rirs), P, C, L, _ptr(seg), _ptr(y), flags, None))
     return y
+
+
+@_restores_device
+def convolve_scene(xs, banks, segs, peaks=None, outs=None):
+    """All renders of one scene in ONE persistent launch (``ss_convolve_scene_f32``; SonicSet.py:61-94 renders its three moving speakers
+    and two static sources one after the other).  xs: n dry signals (T,); banks[i]: (P, C, L) for a moving source (segs[i] = its P - 1
+    segment lengths, sum T) or (C, L) / (1, C, L) for a static one (segs[i] None); peaks[i]: optional one-element device tensor (deferred
+    peak normalisation of that bank); outs: optional n (C, T) float32 device tensors (e.g. rows of a stem stack).  Device tensors only.
+    Returns the list of outputs -- bit-identical to convolve_moving_seg / convolve_fixed called one by one."""
+    import torch
+    lib = _lib.load()
+    n = len(xs)
+    if not (1 <= n <= 8) or len(banks) != n or len(segs) != n:
+        raise ValueError("1..8 sources, one bank and one segment list (or None) per source")
+    dev = xs[0].device
+    xs = [_dev32(torch.as_tensor(x).to(dev), "x").reshape(-1) for x in xs]
+    T = xs[0].shape[0]
+    bk, Ps, sg = [], [], []
+    for i in range(n):
+        b = _dev32(torch.as_tensor(banks[i]).to(dev), "rirs")
+        if b.dim() == 2:
+            b = b[None]
+        if b.dim() != 3:
+            raise ValueError("banks must be (P, C, L) or (C, L)")
+        if segs[i] is None:
+            if b.shape[0] != 1:
+                raise ValueError("a static source has one filter per channel (C, L)")
+            sg.append(None)
+        else:
+            a = np.ascontiguousarray(np.asarray(segs[i], dtype=np.int64).reshape(-1))
+            if a.shape[0] != b.shape[0] - 1 or b.shape[0] < 2:
+                raise ValueError("a moving source needs P >= 2 filters and P - 1 segment lengths")
+            sg.append(a)
+        bk.append(b)
+        Ps.append(int(b.shape[0]))
+    C, L = int(bk[0].shape[1]), int(bk[0].shape[2])
+    if any(x.shape[0] != T for x in xs) or any(b.shape[1] != C or b.shape[2] != L for b in bk):
+        raise ValueError("all sources of a scene share T, C and L")
+    ys = [_out_ct(outs[i] if outs is not None else None, C, T, dev) for i in range(n)]
+    pk = [None] * n
+    if peaks is not None:
+        for i in range(n):
+            p = peaks[i]
+            if p is not None and not (_is_dev(p) and p.dtype == torch.float32 and p.numel() == 1 and p.device == dev):
+                raise ValueError("a peak must be a one-element float32 tensor on the scene's device")
+            pk[i] = p
+    vp = ctypes.c_void_p * n
+    arr = lambda ts: vp(*[ctypes.c_void_p(t.data_ptr()) if t is not None else None for t in ts])
+    seg_arr = vp(*[ctypes.c_void_p(a.ctypes.data) if a is not None else None for a in sg])
+    P_arr = (ctypes.c_int32 * n)(*Ps)
+    _set_device(xs[0])
+    _lib.check(lib.ss_convolve_scene_f32(n, arr(xs), T, arr(bk), P_arr, C, L, seg_arr, arr(pk) if peaks is not None else None, arr(ys),
+                                         _lib.FLAG_DEVICE_PTR, _stream_ptr(xs[0])))
+    return ys
 
 
 @_restores_device
@@ -443,10 +511,12 @@ def kweighted_block_power(audio, coef, lo, hi, norm, layout_tc=True):
 
 
 @_restores_device
-def lufs_norm(audio, coef, lo, hi, block_norm, weights, target_lufs, layout_tc=True):
+def lufs_norm(audio, coef, lo, hi, block_norm, weights, target_lufs, layout_tc=True, result_device=False):
     """Row U in one call (SonicSim_audio.py:68-81): block powers, BS.1770-4 gating, gain and scaling on the device.
     audio (T,), (T,C) / (C,T), or a batch of stems (S,C,T) (channel-first only) with one target per stem.
-    Returns (out like audio, loudness, linear gain, sum(out), sum(audio)) -- scalars, or length-S lists for a batch."""
+    Returns (out like audio, loudness, linear gain, sum(out), sum(audio)) -- scalars, or length-S lists for a batch.
+    result_device=True (device tensors only): nothing comes back to the host -- returns (out, res) with res a float64 device tensor
+    (S, 4) = {loudness, gain, sum(out), sum(audio)} per stem; the call only enqueues work (a scene generator reads it when it wants)."""
     lib = _lib.load()
     coef = np.ascontiguousarray(np.asarray(coef, dtype=np.float64).reshape(2, 6))
     lo = np.ascontiguousarray(np.asarray(lo, dtype=np.int64))
@@ -481,6 +551,14 @@ def lufs_norm(audio, coef, lo, hi, block_norm, weights, target_lufs, layout_tc=T
     tg = np.ascontiguousarray(np.asarray(target_lufs, dtype=np.float64).reshape(-1))
     if tg.shape[0] != S:
         raise ValueError("need one target loudness per stem")
+    if result_device:
+        if not dev:
+            raise ValueError("result_device=True needs device tensors")
+        res_dev = torch.empty((S, 4), dtype=torch.float64, device=a.device)
+        _lib.check(lib.ss_lufs_norm_batch_f32(_ptr(a), _ptr(out), T, C, S, coef.ctypes.data_as(_lib.c_f64p), lo.ctypes.data_as(_lib.c_i64p),
+                                              hi.ctypes.data_as(_lib.c_i64p), nb, float(block_norm), w.ctypes.data_as(_lib.c_f64p),
+                                              tg.ctypes.data_as(_lib.c_f64p), _ptr(res_dev), flags | _lib.FLAG_RESULT_DEVICE, stream))
+        return out, res_dev
     res = (ctypes.c_double * (4 * S))()
     _lib.check(lib.ss_lufs_norm_batch_f32(_ptr(a), _ptr(out), T, C, S, coef.ctypes.data_as(_lib.c_f64p), lo.ctypes.data_as(_lib.c_i64p),
                                           hi.ctypes.data_as(_lib.c_i64p), nb, float(block_norm), w.ctypes.data_as(_lib.c_f64p),

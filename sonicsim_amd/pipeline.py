@@ -57,10 +57,10 @@ def make_scene_inputs(device, scene=0, config="cfg2", defer_norm=True) -> SceneI
     return SceneInputs(spk, st, sc.fs)
 
 
-def _normalise_and_mix(stack, fs, nstem, sirs, snr, out):
+def _normalise_and_mix(stack, fs, nstem, sirs, snr, out, sync=True):
     # row U for all stems in one device call (targets drawn in stem order like successive reference calls);
     # (C,T) stems in place of the reference's transposed (T,C)
-    nstack, gains = A.get_lufs_norm_audio_batch(stack, fs, LUFS_TARGETS[:nstem], allow_many_channels=True)
+    nstack, gains = A.get_lufs_norm_audio_batch(stack, fs, LUFS_TARGETS[:nstem], allow_many_channels=True, sync=sync)
     normed = [nstack[j] for j in range(nstem)]
     spk = nstack[:2].clone()                                                     # 2-speaker separation mixture (the mix scales interferers in place, :113)
     noise = normed[3][None]
@@ -115,26 +115,42 @@ def make_scene_spec(device, scene=0, config="cfg2") -> SceneSpec:
 
 
 class SceneRenderer:
-    """Renders SceneSpecs with reused device buffers: one stem stack (5, C, T) and one bank (P, C, L) -- the three speakers of a
-    scene use the bank buffer one after the other on the stream."""
+    """Renders SceneSpecs with a reused stem stack (5, C, T).  one_launch=True (default): the five banks / IRs of the scene are produced
+    first and all five renders run as ONE persistent launch; False: render by render, the three speakers' banks reuse one block of the
+    caching allocator one after the other."""
 
-    def __init__(self, spec: SceneSpec, device):
+    def __init__(self, spec: SceneSpec, device, one_launch=True):
         import torch
         self.device = device
+        self.one_launch = one_launch          # all five renders of a scene in ONE persistent launch (bit-identical to the separate calls)
         self.stack = torch.empty((5, spec.C, spec.T), dtype=torch.float32, device=device)
 
-    def render(self, spec: SceneSpec, seed: int, sirs=(0.0,), snr=15.0, out=None):
+    def render(self, spec: SceneSpec, seed: int, sirs=(0.0,), snr=15.0, out=None, sync=False):
         """K1 x 3 (bank + tracked peak) -> moving renders with the normalisation deferred; K1 x 2 -> static renders; loudness of
-        the five stems in one call; mix of speakers {1, 2} + noise into ``out`` (or a fresh tensor).  Returns (mix, gains)."""
-        i = 0
-        for k, (x, delay, dgain, seg, rt60) in enumerate(spec.speakers):
-            bank, peak = ops.rir_bank_synth(delay, dgain, spec.L, spec.fs, rt60, (seed * 8 + k) & 0x7FFFFFFF, device=self.device, return_peak=True)
-            ops.convolve_moving_seg(x, bank, seg, out=self.stack[i], bank_peak=peak)
-            del bank                                                   # back to the caching allocator: the next speaker reuses the block
-            i += 1
-        for k, (x, delay, dgain, rt60) in enumerate(spec.statics):
-            h = ops.rir_bank_synth(delay, dgain, spec.L, spec.fs, rt60, (seed * 8 + 4 + k) & 0x7FFFFFFF, device=self.device)[0]
-            ops.convolve_fixed(x, h, out=self.stack[i])
-            i += 1
-        mix, _, gains = _normalise_and_mix(self.stack, spec.fs, 5, sirs, snr, out)
+        the five stems in one call; mix of speakers {1, 2} + noise into ``out`` (or a fresh tensor).  Returns (mix, gains).
+        sync=False (default): nothing in a scene waits for the GPU -- the five loudness gains are a float64 device tensor the caller
+        reads when it writes the scene's metadata; sync=True returns them as Python floats (one synchronisation per scene)."""
+        if self.one_launch and spec.L > 4096:
+            # the provider first (five K1 launches), then ALL five renders in one persistent launch (ss_convolve_scene_f32)
+            xs, banks, segs, peaks = [], [], [], []
+            for k, (x, delay, dgain, seg, rt60) in enumerate(spec.speakers):
+                bank, peak = ops.rir_bank_synth(delay, dgain, spec.L, spec.fs, rt60, (seed * 8 + k) & 0x7FFFFFFF, device=self.device, return_peak=True)
+                xs.append(x); banks.append(bank); segs.append(seg); peaks.append(peak)
+            for k, (x, delay, dgain, rt60) in enumerate(spec.statics):
+                h = ops.rir_bank_synth(delay, dgain, spec.L, spec.fs, rt60, (seed * 8 + 4 + k) & 0x7FFFFFFF, device=self.device)
+                xs.append(x); banks.append(h); segs.append(None); peaks.append(None)
+            ops.convolve_scene(xs, banks, segs, peaks=peaks, outs=[self.stack[i] for i in range(len(xs))])
+            del banks
+        else:
+            i = 0
+            for k, (x, delay, dgain, seg, rt60) in enumerate(spec.speakers):
+                bank, peak = ops.rir_bank_synth(delay, dgain, spec.L, spec.fs, rt60, (seed * 8 + k) & 0x7FFFFFFF, device=self.device, return_peak=True)
+                ops.convolve_moving_seg(x, bank, seg, out=self.stack[i], bank_peak=peak)
+                del bank                                                   # back to the caching allocator: the next speaker reuses the block
+                i += 1
+            for k, (x, delay, dgain, rt60) in enumerate(spec.statics):
+                h = ops.rir_bank_synth(delay, dgain, spec.L, spec.fs, rt60, (seed * 8 + 4 + k) & 0x7FFFFFFF, device=self.device)[0]
+                ops.convolve_fixed(x, h, out=self.stack[i])
+                i += 1
+        mix, _, gains = _normalise_and_mix(self.stack, spec.fs, 5, sirs, snr, out, sync=sync)
         return mix, gains

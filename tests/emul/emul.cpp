@@ -114,6 +114,33 @@ int emul_plan_dump_ex(const int64_t* seg_len, int P, int C, int L, int groups, i
     return (int)t.size();
 }
 
+// the multi-source (scene) planner: segs = the concatenated segment lengths of the moving sources (P[s] - 1 each; nothing for P[s] == 1)
+int emul_plan_scene(const int64_t* segs, const int32_t* Ps, int nsrc, int64_t T, int C, int L, int groups, int tail_pct, int32_t* main_out,
+                    int32_t* out, int max_tasks) {
+    std::vector<std::vector<int64_t>> starts(nsrc);
+    SceneSrc src[8];
+    const int64_t* p = segs;
+    for (int s = 0; s < nsrc; ++s) {
+        starts[s].assign(Ps[s], 0);
+        if (Ps[s] > 1) {
+            int64_t acc = 0;
+            for (int k = 0; k < Ps[s] - 1; ++k) { starts[s][k] = acc; acc += p[k]; }
+            starts[s][Ps[s] - 1] = acc;
+            p += Ps[s] - 1;
+        }
+        src[s].seg_start = starts[s].data();
+        src[s].P = Ps[s];
+    }
+    const int NP = (L + B12 - 1) / B12;
+    std::vector<Task> t;
+    int32_t m = -1;
+    plan_scene_lpt(src, nsrc, T, C, B12, JMAX12, NP, t, groups, tail_pct, &m);
+    if (main_out) *main_out = m;
+    const int n = (int)std::min<size_t>(t.size(), (size_t)max_tasks);
+    for (int i = 0; i < n; ++i) { out[4 * i] = t[i].row; out[4 * i + 1] = t[i].chan; out[4 * i + 2] = t[i].j0; out[4 * i + 3] = t[i].nj; }
+    return (int)t.size();
+}
+
 // planner cross-check: the direct O(P*C) segment planner must emit exactly the tasks of the generic (min/max driven) planner
 // whose row actually owns samples; returns 0 when consistent, otherwise a positive diagnostic code
 int emul_plan_compare(const int64_t* seg_len, int P, int C, int L, int64_t* nfast, int64_t* ngeneric) {

@@ -184,3 +184,65 @@ def test_segment_planner_options_cover_every_sample_once(emul):
                 assert 0 <= m.value <= n and m.value % 8 == 0 and (n < 16 or m.value < n)
             else:
                 assert m.value == n
+
+
+def test_scene_planner_tiles_every_source(emul):
+    """plan.h::plan_scene_lpt (ss_convolve_scene_f32: all renders of a scene in one launch): per source exactly the tasks the single-source
+    planner would emit -- a moving source's rows tile the blocks that hold their samples, a static source covers every block once per
+    channel -- with the source id in the upper half of Task.chan; the per-XCD part is a whole number of rounds."""
+    rng = np.random.default_rng(23)
+    B = 4096
+    i32 = ctypes.POINTER(ctypes.c_int32)
+    for case in range(8):
+        nsrc = int(rng.integers(1, 6))
+        C = int(rng.integers(1, 4))
+        L = int(rng.integers(9000, 50000))
+        T = int(rng.integers(50000, 400000))
+        Ps, segs = [], []
+        for s_ in range(nsrc):
+            Pn = 1 if rng.random() < 0.35 else int(rng.integers(2, 40))
+            Ps.append(Pn)
+            if Pn > 1:
+                cuts = np.sort(rng.integers(0, T + 1, Pn - 2))
+                segs.append(np.diff(np.concatenate([[0], cuts, [T]])).astype(np.int64))
+        seg_cat = np.concatenate(segs) if segs else np.zeros(1, np.int64)
+        Pa = np.array(Ps, np.int32)
+        for tail in (0, 12):
+            out = np.zeros((400000, 4), np.int32)
+            m = ctypes.c_int32(-7)
+            n = emul.emul_plan_scene(P(seg_cat, ip), P(Pa, i32), nsrc, T, C, L, 8, tail, ctypes.byref(m), P(out, i32), len(out))
+            assert 0 < n <= len(out)
+            t = out[:n]
+            assert 0 <= m.value <= n and m.value % 8 == 0 and (tail == 0 or n < 16 or m.value < n)
+            seen = {}
+            for row, chan, j0, nj in t:
+                assert 1 <= nj <= 4 and 0 <= (chan & 0xFFFF) < C and 0 <= (chan >> 16) < nsrc
+                seen.setdefault((chan >> 16, row, chan & 0xFFFF), []).append((j0, nj))
+            nblk = (T + B - 1) // B
+            k = 0
+            for s_ in range(nsrc):
+                if Ps[s_] == 1:
+                    for c in range(C):
+                        got = sorted(seen.pop((s_, 0, c)))
+                        pos = 0
+                        for j0, nj in got:
+                            assert j0 == pos
+                            pos += nj
+                        assert pos == nblk
+                    continue
+                start = np.concatenate([[0], np.cumsum(segs[k])])
+                k += 1
+                for r in range(Ps[s_]):
+                    a0 = start[r - 1] if r > 0 else start[r]
+                    a2 = start[r + 1] if r < Ps[s_] - 1 else start[r]
+                    for c in range(C):
+                        got = sorted(seen.pop((s_, r, c), []))
+                        if a2 <= a0:
+                            assert not got
+                            continue
+                        pos = a0 // B
+                        for j0, nj in got:
+                            assert j0 == pos
+                            pos += nj
+                        assert pos * B >= a2 and (pos - 1) * B < a2
+            assert not seen

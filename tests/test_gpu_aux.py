@@ -385,3 +385,18 @@ def test_generate_rir_combination_product_glue_on_ragged_irs(gpu, monkeypatch):
             assert np.array_equal(np.array(calls[0]["rcv"], dtype=np.float64), g[f"rcv_order{case}"])
             assert np.array_equal(np.array(calls[0]["rot"], dtype=np.float64), g[f"rot_order{case}"])
             assert calls[0]["channel_order"] == int(g[f"channel_order{case}"])
+
+
+def test_lufs_batch_without_synchronisation(gpu):
+    """SS_FLAG_RESULT_DEVICE: the batched loudness call leaves {loudness, gain, sums} on the device (no host synchronisation); the scaled
+    stems are bit-identical to the synchronous call's and the gains agree to the last bit of their float64 sums"""
+    from sonicsim_amd import SonicSim_audio as A
+    rng = np.random.default_rng(31)
+    stack = torch.from_numpy((rng.standard_normal((3, 4, 48000)) * np.array([0.1, 0.02, 0.3])[:, None, None]).astype(np.float32)).to(gpu)
+    np.random.seed(5)
+    out_s, gains_s = A.get_lufs_norm_audio_batch(stack, 16000, (-17, -24, -29))
+    np.random.seed(5)
+    out_a, gains_a = A.get_lufs_norm_audio_batch(stack, 16000, (-17, -24, -29), sync=False)
+    assert torch.is_tensor(gains_a) and gains_a.is_cuda and gains_a.dtype == torch.float64 and gains_a.shape == (3,)
+    assert torch.equal(out_s, out_a)
+    assert np.array_equal(gains_a.cpu().numpy(), np.array(gains_s, dtype=np.float64))

@@ -1,0 +1,60 @@
+"""ss_convolve_scene_f32: all renders of a scene (moving and static sources) in ONE persistent launch are bit-identical to the
+separate calls (SonicSet.py:61-94 renders them one after the other)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _inputs(gpu, T, Ps, C, L, seed):
+    rng = np.random.default_rng(seed)
+    xs, banks, segs, peaks = [], [], [], []
+    for P in Ps:
+        xs.append(torch.from_numpy((rng.standard_normal(T) * 0.1).astype(np.float32)).to(gpu))
+        h = (rng.standard_normal((P, C, L)) * np.exp(-4.0 * np.arange(L) / L)[None, None, :]).astype(np.float32)
+        banks.append(torch.from_numpy(h).to(gpu))
+        if P > 1:
+            cuts = np.sort(rng.integers(0, T + 1, P - 2))
+            segs.append(np.diff(np.concatenate([[0], cuts, [T]])).astype(np.int64))
+            peaks.append(torch.tensor([float(np.abs(h).max())], dtype=torch.float32, device=gpu))
+        else:
+            segs.append(None)
+            peaks.append(None)
+    return xs, banks, segs, peaks
+
+
+@pytest.mark.parametrize("static_lists", [False, True])
+def test_scene_launch_is_bit_identical_to_separate_renders(gpu, static_lists):
+    from sonicsim_amd import ops
+    ops.set_task_queue(not static_lists)
+    try:
+        for (T, Ps, C, L, seed) in ((150000, (9, 14, 6, 1, 1), 3, 9000, 1), (70000, (1, 5), 2, 20000, 2), (200000, (11,), 4, 12000, 3),
+                                    (90000, (1, 1, 1), 8, 8200, 4)):
+            xs, banks, segs, peaks = _inputs(gpu, T, Ps, C, L, seed)
+            want = []
+            for x, b, sg, pk in zip(xs, banks, segs, peaks):
+                want.append(ops.convolve_fixed(x, b[0]) if sg is None else ops.convolve_moving_seg(x, b, sg, bank_peak=pk))
+            stack = torch.full((len(Ps), C, T), float("nan"), dtype=torch.float32, device=gpu)
+            got = ops.convolve_scene(xs, [b if sg is not None else b[0] for b, sg in zip(banks, segs)], segs, peaks=peaks,
+                                     outs=[stack[i] for i in range(len(Ps))])
+            for i in range(len(Ps)):
+                assert got[i].data_ptr() == stack[i].data_ptr()
+                assert torch.equal(got[i], want[i]), (Ps, i)
+            again = ops.convolve_scene(xs, banks, segs, peaks=peaks)                 # fresh outputs, (1, C, L) static banks: same bits
+            assert all(torch.equal(a, w) for a, w in zip(again, want))
+    finally:
+        ops.set_task_queue(True)
+
+
+def test_scene_launch_argument_checks(gpu):
+    from sonicsim_amd import ops
+    xs, banks, segs, _ = _inputs(gpu, 60000, (4, 1), 2, 9000, 7)
+    with pytest.raises(ValueError):
+        ops.convolve_scene(xs, banks, [segs[0][:-1], None])                           # wrong number of segment lengths
+    with pytest.raises(ValueError):
+        ops.convolve_scene(xs, banks, [segs[0] + 1, None])                            # sum != T
+    with pytest.raises(ValueError):
+        ops.convolve_scene(xs, [banks[0][:, :, :3000], banks[1][:, :, :3000]], segs)  # filters too short for the assembly engine
+    with pytest.raises(ValueError):
+        ops.convolve_scene(xs * 5, banks * 5, segs * 5)                               # more than 8 sources
