@@ -454,6 +454,7 @@ def run_scenes(args, rank, local_rank, world, dev):
     import torch
     import torch.distributed as dist
 
+    from sonicsim_amd import SonicSim_audio as A
     from sonicsim_amd import parallel, pipeline
 
     per_rank = args.steps
@@ -477,7 +478,7 @@ def run_scenes(args, rank, local_rank, world, dev):
             gains.append(rend.render(spec, seed=base + j, sirs=sir, snr=snr, out=out)[1])      # (5,) float64 on the device: no wait per scene
             if sg is not None:
                 sg.submit(j)
-        run.gains = torch.stack(gains).cpu() if gains else None       # every scene's five loudness gains reach the host inside the timed region
+        run.gains = A.lufs_gains_from_result(torch.stack(gains).cpu().numpy()) if gains else None    # every scene's five loudness gains reach the host inside the timed region
         return sg.finish() if sg is not None else None
 
     lo = parallel.shard_range(total, rank, world)[0] if total else 0

@@ -44,6 +44,7 @@ extern "C" {
 #define SS_FLAG_LAYOUT_TC 0x100u  /* audio is [T][C] instead of [C][T] (loudness / mix calls) */
 #define SS_FLAG_META_DEVICE 0x1000u /* ss_rir_bank_synth*_f32 with SS_FLAG_DEVICE_PTR: SsRirParams.delay / .dgain are DEVICE pointers (no staging copy) */
 #define SS_FLAG_RESULT_DEVICE 0x2000u /* ss_lufs_norm_batch_f32 with SS_FLAG_DEVICE_PTR: `result` is a DEVICE array of 4 * S doubles; the call only enqueues work (no synchronisation) */
+#define SS_FLAG_KEEP_SPEAKERS 0x4000u /* ss_mix_f32: do not write the scaled interferers back into `speakers` (read-only input; the mix is the only output) */
 #define SS_FLAG_ASYNC_PLAN 0x800u /* ss_convolve_moving_f32 with device pointers: plan the explicit schedule on the device (no host synchronisation) */
 
 int ss_version(void);

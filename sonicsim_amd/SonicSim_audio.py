@@ -185,9 +185,10 @@ def lufs_norm(data, sr, norm=-6, allow_many_channels: bool = False, channel_firs
 def get_lufs_norm_audio_batch(stems, sr=16000, lufs=(-6,), allow_many_channels: bool = False, sync: bool = True):
     """Extension: ``get_lufs_norm_audio`` for a stack of stems (S, C, T) in ONE device call.  The class loudness of stem i
     is drawn from the global NumPy RNG in stem order, exactly as S successive reference calls (:83-86) would draw them.
-    Returns (normalised stack (S, C, T), [gain_0, ...]).  sync=False (device stacks): the call only enqueues work and the gains come
-    back as a float64 device tensor (S,) -- sum(out) / sum(in) like the reference's returned gain, 0 where sum(in) is 0 -- for a
-    generator that keeps rendering the next scene instead of waiting for this one's numbers (no "loudness is inf" print then)."""
+    Returns (normalised stack (S, C, T), [gain_0, ...]).  sync=False (device stacks): the call only enqueues work and returns the raw
+    result record instead of the gains -- a float64 device tensor (S, 4) = {loudness, linear gain, sum(out), sum(in)} per stem, for a
+    generator that keeps rendering the next scene instead of waiting for this one's numbers; ``lufs_gains_from_result`` turns fetched
+    records into the reference's returned gains (no "loudness is inf" print in this mode)."""
     S, C, T = stems.shape
     if len(lufs) != S:
         raise ValueError("one nominal loudness per stem")
@@ -197,12 +198,20 @@ def get_lufs_norm_audio_batch(stems, sr=16000, lufs=(-6,), allow_many_channels: 
     if not sync:
         import torch
         out, res = ops.lufs_norm(stems, _kw_coef(float(sr)), lo, hi, block_size * sr, weights, targets, layout_tc=False, result_device=True)
-        return out, torch.where(res[:, 3] != 0, res[:, 2] / res[:, 3], torch.zeros_like(res[:, 2]))
+        return out, res                 # (S, 4) float64 on the device: {loudness, linear gain, sum(out), sum(in)}; see lufs_gains_from_result
     out, loud, _lin, n, d = ops.lufs_norm(stems, _kw_coef(float(sr)), lo, hi, block_size * sr, weights, targets, layout_tc=False)
     for l in loud:
         if math.isinf(l):
             print("loudness is inf")
     return out, [ni / di if di else 0.0 for ni, di in zip(n, d)]
+
+
+def lufs_gains_from_result(res):
+    """(..., 4) result records of ``get_lufs_norm_audio_batch(sync=False)`` (any array-like on the host) -> the gains the reference returns
+    (SonicSim_audio.py:80: sum(out) / sum(in), 0 where sum(in) is 0)."""
+    r = np.asarray(res, dtype=np.float64)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        return np.where(r[..., 3] != 0, r[..., 2] / r[..., 3], 0.0)
 
 
 def get_lufs_norm_audio(audio, sr=16000, lufs=-6, allow_many_channels: bool = False, channel_first: bool = False):

@@ -23,6 +23,7 @@ FLAG_GEOM_ASM = 0x400
 FLAG_ASYNC_PLAN = 0x800
 FLAG_META_DEVICE = 0x1000
 FLAG_RESULT_DEVICE = 0x2000
+FLAG_KEEP_SPEAKERS = 0x4000
 
 SS_EINVAL, SS_EHIP, SS_ENOMEM, SS_ENODEV = -1, -2, -3, -4
 

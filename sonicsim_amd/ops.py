@@ -441,12 +441,14 @@ def rms_db(x):
 
 
 @_restores_device
-def mix(speaker_wav, noise_wav, sirs, snr, want_gains=True, out=None):
+def mix(speaker_wav, noise_wav, sirs, snr, want_gains=True, out=None, keep_speakers=False):
     """Row M (movingdatamodule.py:105-124).  speaker_wav (S,...), noise_wav (N,...) same trailing shape.
     Returns (mix, speaker_wav_scaled, gains).  A contiguous float32 device ``speaker_wav`` is scaled IN PLACE like the reference
     (:113); any other device input is first copied to that form (the returned tensor is then the scaled copy).
     want_gains=False skips the D2H copy of the gains and with it the only host synchronisation (gains is None).
-    out (device form): a contiguous float32 tensor shaped like one stem to receive the mix (e.g. a gather slot)."""
+    out (device form): a contiguous float32 tensor shaped like one stem to receive the mix (e.g. a gather slot).
+    keep_speakers=True (device form): ``speaker_wav`` is read only -- the interferers are scaled on the fly for the mix and not written
+    back (a scene generator keeps its normalised stems without cloning them first); the returned speaker tensor is then the input."""
     lib = _lib.load()
     sirs = np.ascontiguousarray(np.asarray(sirs, dtype=np.float32).reshape(-1))
     if _is_dev(speaker_wav):
@@ -464,7 +466,8 @@ def mix(speaker_wav, noise_wav, sirs, snr, want_gains=True, out=None):
         gains = np.zeros(S, dtype=np.float32) if want_gains else None
         _set_device(spk)
         _lib.check(lib.ss_mix_f32(_ptr(spk), S, _ptr(noi), N, n, sirs.ctypes.data_as(_lib.c_f32p), float(snr), _ptr(out),
-                                  gains.ctypes.data_as(_lib.c_f32p) if want_gains else None, _lib.FLAG_DEVICE_PTR, _stream_ptr(spk)))
+                                  gains.ctypes.data_as(_lib.c_f32p) if want_gains else None,
+                                  _lib.FLAG_DEVICE_PTR | (_lib.FLAG_KEEP_SPEAKERS if keep_speakers else 0), _stream_ptr(spk)))
         return out, spk, gains
     spk = np.array(_np32(speaker_wav, "speaker_wav"), copy=True)
     noi = _np32(noise_wav, "noise_wav")

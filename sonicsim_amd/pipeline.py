@@ -62,9 +62,9 @@ def _normalise_and_mix(stack, fs, nstem, sirs, snr, out, sync=True):
     # (C,T) stems in place of the reference's transposed (T,C)
     nstack, gains = A.get_lufs_norm_audio_batch(stack, fs, LUFS_TARGETS[:nstem], allow_many_channels=True, sync=sync)
     normed = [nstack[j] for j in range(nstem)]
-    spk = nstack[:2].clone()                                                     # 2-speaker separation mixture (the mix scales interferers in place, :113)
-    noise = normed[3][None]
-    mix, _ = mixing.mix_sources(spk, noise, np.asarray(sirs, dtype=np.float32), float(snr), out=out)   # row M
+    noise = normed[3][None]                                                      # 2-speaker separation mixture; the reference scales the interferer in place
+    mix, _ = mixing.mix_sources(nstack[:2], noise, np.asarray(sirs, dtype=np.float32), float(snr), out=out,      # (:113) -- here the stems stay as
+                                keep_speakers=True)                                                               # normalised (no clone): row M
     return mix, normed, gains
 
 

@@ -397,6 +397,25 @@ def test_lufs_batch_without_synchronisation(gpu):
     out_s, gains_s = A.get_lufs_norm_audio_batch(stack, 16000, (-17, -24, -29))
     np.random.seed(5)
     out_a, gains_a = A.get_lufs_norm_audio_batch(stack, 16000, (-17, -24, -29), sync=False)
-    assert torch.is_tensor(gains_a) and gains_a.is_cuda and gains_a.dtype == torch.float64 and gains_a.shape == (3,)
+    assert torch.is_tensor(gains_a) and gains_a.is_cuda and gains_a.dtype == torch.float64 and gains_a.shape == (3, 4)
     assert torch.equal(out_s, out_a)
-    assert np.array_equal(gains_a.cpu().numpy(), np.array(gains_s, dtype=np.float64))
+    assert np.array_equal(A.lufs_gains_from_result(gains_a.cpu().numpy()), np.array(gains_s, dtype=np.float64))
+
+
+def test_mix_keep_speakers_and_vector_path(gpu):
+    """ss_mix_f32 with SS_FLAG_KEEP_SPEAKERS: same mix bits, speakers untouched; the 16-byte path (n % 4 == 0, aligned) and the scalar path
+    (odd length) both agree with the NumPy oracle of movingdatamodule.py:105-124"""
+    from sonicsim_amd import ops
+    rng = np.random.default_rng(77)
+    for T in (64000, 63999):
+        spk = (rng.standard_normal((3, 2, T)) * 0.1).astype(np.float32)
+        noi = (rng.standard_normal((1, 2, T)) * 0.05).astype(np.float32)
+        sirs = np.array([2.5, -4.0], np.float32)
+        ref_mix, ref_spk = OM.mix(spk.copy(), noi, sirs, 12.0)
+        a = torch.from_numpy(spk.copy()).to(gpu)
+        m1, s1, _ = ops.mix(a, torch.from_numpy(noi).to(gpu), sirs, 12.0, want_gains=False)
+        b = torch.from_numpy(spk.copy()).to(gpu)
+        m2, s2, _ = ops.mix(b, torch.from_numpy(noi).to(gpu), sirs, 12.0, want_gains=False, keep_speakers=True)
+        assert torch.equal(m1, m2)
+        assert np.array_equal(b.cpu().numpy(), spk)                      # untouched
+        assert rel_rms(m1.cpu().numpy(), ref_mix) < 1e-6 and rel_rms(s1.cpu().numpy(), ref_spk) < 1e-6
