@@ -241,7 +241,10 @@ __global__ __launch_bounds__(1024) void k_plan_explicit(PlanDevArgs a) {
     __shared__ long long sh[17];
     __shared__ int gcount[64];
     __shared__ int crange[2];
+    __shared__ int oor_tile;               // first tile of THIS call with an index out of range (status[3..4]: per call, not latched)
     const int tid = threadIdx.x, nt = blockDim.x;
+    if (tid == 0) oor_tile = INT32_MAX;
+    __syncthreads();
     // ---- 1: per output block min/max of idx, range check, clamp
     for (int j = tid; j < a.nblk; j += nt) {
         int lo = INT32_MAX, hi = INT32_MIN;
@@ -251,6 +254,7 @@ __global__ __launch_bounds__(1024) void k_plan_explicit(PlanDevArgs a) {
                 const int l = a.bmin[fb], h = a.bmax[fb];
                 if (l < 0 || h > a.P - 2) {
                     if (atomicCAS(&a.status[0], 0, 1) == 0) a.status[1] = (int32_t)(fb < INT32_MAX ? fb : INT32_MAX);
+                    atomicMin(&oor_tile, (int)(fb < INT32_MAX ? fb : INT32_MAX - 1));
                 }
                 lo = l < lo ? l : lo;
                 hi = h > hi ? h : hi;
@@ -265,6 +269,7 @@ __global__ __launch_bounds__(1024) void k_plan_explicit(PlanDevArgs a) {
     for (int r = tid; r < a.P; r += nt) { a.first[r] = INT32_MAX; a.last[r] = -1; }
     if (tid < 64) gcount[tid] = 0;
     __syncthreads();
+    if (tid == 0) { a.status[3] = oor_tile != INT32_MAX ? 1 : 0; a.status[4] = oor_tile != INT32_MAX ? oor_tile : 0; }
     // ---- 2: first / last block of every row
     for (int j = tid; j < a.nblk; j += nt) {
         const int lo = a.lo[j], hi = a.hi[j];
@@ -1502,6 +1507,7 @@ struct Ctx {
     void* gw_cached_dev = nullptr;
     void* kw_cached_dev = nullptr;
     int num_cu = 0;
+    bool last_dev_planned = false;        // the last render() on this device planned its schedule on the device (ss_plan_status_last is about it)
     int32_t* async_status = nullptr;      // device: {code, where} latched by k_plan_explicit (SS_FLAG_ASYNC_PLAN), read by ss_async_status
     std::mutex mu;          // one lock per device context: entry points are re-entrant per device (one host thread per GPU works)
 };
@@ -1780,6 +1786,7 @@ int render(int mode, const float* x, int64_t T, const float* bank, int32_t P, in
     }
     // explicit schedule planned on the device (assembly engine, device pointers): nothing comes back to the host
     const bool dev_plan = mode == COEF_EXPLICIT && g14 && dev && (flags & SS_FLAG_ASYNC_PLAN);
+    c->last_dev_planned = dev_plan;
     int32_t* dplan_out = nullptr;
     if (dev_plan) {
         const int nblk = (int)((T + BB - 1) / BB);
@@ -1793,8 +1800,8 @@ int render(int mode, const float* x, int64_t T, const float* bank, int32_t P, in
         if ((rc = ws_ensure(c, WS_DPLAN, o_end))) return rc;
         if ((rc = ws_ensure(c, WS_DTASKS, 16 + sizeof(Task) * (size_t)cap_rows * C))) return rc;
         if (!c->async_status) {
-            HIPCHK(hipMalloc((void**)&c->async_status, 16));
-            HIPCHK(hipMemsetAsync(c->async_status, 0, 16, stream));
+            HIPCHK(hipMalloc((void**)&c->async_status, 32));
+            HIPCHK(hipMemsetAsync(c->async_status, 0, 32, stream));
         }
         char* base = (char*)c->ws[WS_DPLAN];
         PlanDevArgs pa;
@@ -2026,6 +2033,7 @@ int render_scene(int nsrc, const float* const* xs, int64_t T, const float* const
     hipStream_t stream = (hipStream_t)stream_;
     if ((rc = stream_enter(c, stream))) return rc;
     if ((rc = load_mod13(c, c->dynq))) return rc;
+    c->last_dev_planned = false;
     const int M = (int)((T + B12 - 1) / B12);
     const int NPart = (L + B12 - 1) / B12;
     // ---- segment tables (host) + task list
@@ -2211,6 +2219,29 @@ int ss_async_status(int32_t* code, int64_t* where, void* stream_) {
     if (h[0]) HIPCHK(hipMemsetAsync(c->async_status, 0, 16, stream));
     if (code) *code = h[0];
     if (where) *where = h[0] == 1 ? (int64_t)h[1] * DTILE : (int64_t)h[1];
+    return SS_OK;
+}
+
+int ss_plan_status_last(int32_t* out_of_range, int64_t* where, int32_t* too_irregular, void* stream_) {
+    Ctx* c;
+    int rc = get_ctx(&c);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lock(c->mu);
+    if (out_of_range) *out_of_range = 0;
+    if (where) *where = 0;
+    if (too_irregular) *too_irregular = 0;
+    if (!c->async_status || !c->last_dev_planned) {      // the last render validated (or had nothing to validate) on the host: -1 = "not device-planned"
+        if (out_of_range) *out_of_range = -1;
+        return SS_OK;
+    }
+    hipStream_t stream = (hipStream_t)stream_;
+    if (c->have_last && c->last_stream != stream) HIPCHK(hipStreamSynchronize(c->last_stream));
+    int32_t h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    HIPCHK(hipMemcpyAsync(h, c->async_status, 32, hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    if (out_of_range) *out_of_range = h[3];
+    if (where) *where = (int64_t)h[4] * DTILE;
+    if (too_irregular) *too_irregular = h[2];
     return SS_OK;
 }
 

@@ -129,11 +129,16 @@ def convolve_moving(x, rirs, idx, w, path=None, out=None, validate=True):
             # buffer falls through to the host-planned path below.
             _lib.check(lib.ss_convolve_moving_f32(_ptr(x), T, _ptr(rirs), P, C, L, _ptr(idx), _ptr(w), _ptr(y),
                                                   flags | _lib.FLAG_DEVICE_PTR | _lib.FLAG_ASYNC_PLAN, _stream_ptr(x)))
-            code, where = async_status(x)
-            if code == 0:
+            oor, where, irregular = ctypes.c_int32(0), ctypes.c_int64(0), ctypes.c_int32(0)
+            _lib.check(lib.ss_plan_status_last(ctypes.byref(oor), ctypes.byref(where), ctypes.byref(irregular), _stream_ptr(x)))   # THIS call's outcome
+            if oor.value < 0:
+                return y                          # the library ignored the flag (another engine): it validated on the host before rendering
+            if oor.value or irregular.value:
+                async_status(x)                   # (this call also latched its error for ss_async_status pollers: clear it, it is reported here)
+            if oor.value:
+                raise ValueError(f"interp_index out of range [0, {P - 2}] near sample {where.value} (the output buffer holds no valid render)")
+            if not irregular.value:
                 return y
-            if code == 1:
-                raise ValueError(f"interp_index out of range [0, {P - 2}] near sample {where} (the output buffer holds no valid render)")
         _lib.check(lib.ss_convolve_moving_f32(_ptr(x), T, _ptr(rirs), P, C, L, _ptr(idx), _ptr(w), _ptr(y),
                                               flags | _lib.FLAG_DEVICE_PTR | (0 if validate else _lib.FLAG_ASYNC_PLAN), _stream_ptr(x)))
         return y

@@ -111,3 +111,23 @@ def test_planner_capacity_is_reported():
     sel = slice(100000, 101000)
     ref = O.convolve_moving_receiver(x.cpu().numpy(), bank.cpu().numpy(), idx, w)
     assert O.rel_rms(y_sync.cpu().numpy()[:, sel], ref[:, sel]) <= 1e-4
+
+
+def test_validating_call_is_not_fooled_by_an_older_unpolled_error():
+    """ops.convolve_moving(validate=True) plans optimistically on the device and reads THIS call's outcome (ss_plan_status_last): an error
+    latched by an earlier validate=False render that nobody polled must not make a valid call raise, and an invalid call must raise even
+    when the latched word is already taken"""
+    T, P, C, L = 60000, 6, 1, 9000
+    ops, rng, dev, x, bank = _setup(T, P, C, L, 5)
+    idx = np.minimum(np.arange(T) // 12000, P - 2).astype(np.int64)
+    w = rng.random(T).astype(np.float32)
+    bad = idx.copy()
+    bad[41000:41003] = P - 1
+    di, db, dw = torch.from_numpy(idx).to(dev), torch.from_numpy(bad).to(dev), torch.from_numpy(w).to(dev)
+    ops.convolve_moving(x, bank, db, dw, path="asm", validate=False)          # latches code 1, not polled
+    good = ops.convolve_moving(x, bank, di, dw, path="asm")                    # valid: must not raise
+    assert torch.isfinite(good).all()
+    with pytest.raises(ValueError, match="out of range"):
+        ops.convolve_moving(x, bank, db, dw, path="asm")                       # invalid: raises although the latched word was set before
+    assert torch.equal(ops.convolve_moving(x, bank, di, dw, path="asm"), good)
+    ops.async_status()
