@@ -58,3 +58,46 @@ def test_scene_launch_argument_checks(gpu):
         ops.convolve_scene(xs, [banks[0][:, :, :3000], banks[1][:, :, :3000]], segs)  # filters too short for the assembly engine
     with pytest.raises(ValueError):
         ops.convolve_scene(xs * 5, banks * 5, segs * 5)                               # more than 8 sources
+
+
+def test_two_host_threads_on_their_own_streams(gpu):
+    """Threading contract of the C-ABI (ctypes releases the GIL; one lock per device context, a stream switch serialises against
+    the previous stream): two host threads, each on its own HIP stream, issue renders, bank syntheses with the tracked peak and scene
+    launches concurrently -- every result equals the single-threaded one bit for bit (plan staging, the K1 arrival ticket and the
+    workspace are shared state)."""
+    import threading
+    from sonicsim_amd import ops
+    xs, banks, segs, peaks = _inputs(gpu, 120000, (7, 5, 1), 3, 9000, 11)
+    rng = np.random.default_rng(5)
+    delay = rng.integers(5, 200, (6, 3)).astype(np.int32)
+    dgain = rng.uniform(0.2, 1.5, (6, 3)).astype(np.float32)
+    want_r = [ops.convolve_moving_seg(xs[i], banks[i], segs[i], bank_peak=peaks[i]) for i in (0, 1)]
+    want_s = ops.convolve_scene(xs, banks, segs, peaks=peaks)
+    want_b, want_p = ops.rir_bank_synth(delay, dgain, 12000, 16000, 0.5, 42, device=gpu, return_peak=True)
+    torch.cuda.synchronize()
+    errors = []
+
+    def worker(k):
+        try:
+            st = torch.cuda.Stream(device=gpu)
+            with torch.cuda.stream(st):
+                for it in range(12):
+                    y = ops.convolve_moving_seg(xs[k], banks[k], segs[k], bank_peak=peaks[k])
+                    b, p = ops.rir_bank_synth(delay, dgain, 12000, 16000, 0.5, 42, device=gpu, return_peak=True)
+                    sc = ops.convolve_scene(xs, banks, segs, peaks=peaks)
+                    st.synchronize()
+                    if not torch.equal(y, want_r[k]):
+                        errors.append((k, it, "render"))
+                    if not (torch.equal(b, want_b) and float(p) == float(want_p)):
+                        errors.append((k, it, "bank / peak"))
+                    if not all(torch.equal(a, w) for a, w in zip(sc, want_s)):
+                        errors.append((k, it, "scene"))
+        except Exception as e:                                   # noqa: BLE001
+            errors.append((k, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in (0, 1)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[:5]
