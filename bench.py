@@ -432,7 +432,9 @@ def run_cfg2(args, rank, local_rank, world, dev):
                      "xspec_ms_all_windows": dist_stats(all_xs),
                      "xspec_avg_launch_ms": ms_xs / max(1, n_xs),
                      "timed_launches": n_os, "launches_in_timed_region": n_os_all,
-                     "gpu_ms_per_render_kernels": avg_launch_ms * launches_per_render + ms_xs / max(1, n_xs)},
+                     "xspec_note": "event pairs around a short kernel also time the boundary behind it: the spectra kernel is 13-17 us in the "
+                                   "rocprofv3 kernel trace (profiles/r03v/kernel_stats.csv); the sum of the two event figures can therefore exceed "
+                                   "ms_per_step of the value windows, which carry no events"},
     }
     if world == 1 and args.cpu_seconds > 0:
         legs, yref = cpu_baselines(sc, seg, bank.cpu().numpy(), args.cpu_seconds, all_cores=not args.no_all_cores)
