@@ -5,6 +5,7 @@
 // Build: hipcc --offload-arch=gfx950 -O3 agpr_rate.hip -o agpr_rate
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <string>
 typedef float c32 __attribute__((ext_vector_type(2)));
 #define REP8(x) x x x x x x x x
 
@@ -50,8 +51,12 @@ template <int KIND> void run(const char* name, int threads, int ninst_per_rep) {
     float ms; hipEventElapsedTime(&ms, a, b);
     long long hc; hipMemcpy(&hc, cyc, 8, hipMemcpyDeviceToHost);
     const double ninst = (double)iters * 8.0 * ninst_per_rep;
-    printf("%-44s %d wave(s)/SIMD: shader cycles per instruction per wave %.2f -> per SIMD %.2f\n", name, threads / 256, (double)hc / ninst,
-           (double)hc / ninst / (threads / 256));
+    // wall clock: instructions per second per SIMD -> with the clock implied by (cycles counted / time) of workgroup 0
+    const double secs = ms * 1e-3, clk = (double)hc / secs;            // workgroup 0 runs for (almost) the whole kernel
+    const double tflops = KIND == 0 ? ninst * (threads / 64.0) * grid * 256.0 / secs * 1e-12 : 0.0;      // packed FMA: 2 x 2 x 64 flop per wave-instruction
+    printf("%-44s %d wave(s)/SIMD: s_memtime cycles per instruction per wave %.2f -> per SIMD %.2f | kernel %.1f us, implied clock %.2f GHz%s\n", name,
+           threads / 256, (double)hc / ninst, (double)hc / ninst / (threads / 256), ms * 1e3, clk * 1e-9,
+           KIND == 0 ? (std::string(", chip ") + std::to_string(tflops).substr(0, 6) + " TFLOP/s").c_str() : "");
     hipFree(out); hipFree(cyc);
 }
 
