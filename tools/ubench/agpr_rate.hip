@@ -54,9 +54,12 @@ template <int KIND> void run(const char* name, int threads, int ninst_per_rep) {
     // wall clock: instructions per second per SIMD -> with the clock implied by (cycles counted / time) of workgroup 0
     const double secs = ms * 1e-3, clk = (double)hc / secs;            // workgroup 0 runs for (almost) the whole kernel
     const double tflops = KIND == 0 ? ninst * (threads / 64.0) * grid * 256.0 / secs * 1e-12 : 0.0;      // packed FMA: 2 x 2 x 64 flop per wave-instruction
-    printf("%-44s %d wave(s)/SIMD: s_memtime cycles per instruction per wave %.2f -> per SIMD %.2f | kernel %.1f us, implied clock %.2f GHz%s\n", name,
-           threads / 256, (double)hc / ninst, (double)hc / ninst / (threads / 256), ms * 1e3, clk * 1e-9,
-           KIND == 0 ? (std::string(", chip ") + std::to_string(tflops).substr(0, 6) + " TFLOP/s").c_str() : "");
+    // the first wave's s_memtime count is the OLDER wave's view (it keeps its issue slots, the younger wave of the pair gets the rest):
+    // the per-SIMD rate comes from the wall clock of the whole launch
+    printf("%-44s %d wave(s)/SIMD: first wave %.2f s_memtime cycles per instruction | launch %.1f us = %.2f ns per instruction per SIMD%s\n", name,
+           threads / 256, (double)hc / ninst, ms * 1e3, secs * 1e9 / (ninst * (threads / 256)),
+           KIND == 0 ? (std::string(" = ") + std::to_string(tflops).substr(0, 6) + " TFLOP/s chip-wide").c_str() : "");
+    (void)clk;
     hipFree(out); hipFree(cyc);
 }
 
