@@ -135,6 +135,17 @@ def test_loudness_oracle_calibration():
         O.integrated_loudness(np.zeros((fs, 8)), fs)
 
 
+def test_loudness_oracle_ebu_tech_3341_cases():
+    """Known-answer tests of the BS.1770-4 restatement that do not depend on pyloudnorm (absent here): the integrated-
+    loudness cases 1-5 of EBU Tech 3341, whose expected readings are published (+-0.1 LU) -- calibration, relative gate, absolute gate."""
+    from oracle import loudness as O
+    from util import ebu3341_case
+    for case in (1, 2, 3, 4, 5):
+        x, want = ebu3341_case(case)
+        got = O.integrated_loudness(x, 48000)
+        assert abs(got - want) <= 0.1, (case, got)
+
+
 def test_synth_scene_shapes():
     from sonicsim_amd import synth
     sc = synth.make_scene("tiny")

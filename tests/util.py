@@ -85,3 +85,24 @@ def golden_clip(name):
     tone = np.sin(2 * np.pi * rng.uniform(100, 3000) * t)[None, :] * rng.uniform(0.05, 0.3)
     x = tone + 0.02 * rng.standard_normal((C, T))
     return x.astype(np.float32), sr
+
+
+def ebu3341_case(case, fs=48000):
+    """EBU Tech 3341 (EBU Mode loudness meter conformance) test signals for the INTEGRATED loudness: stereo 1 kHz sine, the same phase in
+    both channels, level sequences in dBFS (peak level of the sine).  Published expectation: every case reads the stated value within
+    +-0.1 LU.  Returns ((T, 2) float32, expected LUFS).
+      1: -23 dBFS, 20 s            -> -23.0      2: -33 dBFS, 20 s            -> -33.0
+      3: -36 (10 s), -23 (60 s), -36 (10 s)                                   -> -23.0   (relative gate removes the quiet parts)
+      4: -72 (10 s), -36 (10 s), -23 (60 s), -36 (10 s), -72 (10 s)           -> -23.0   (absolute gate as well)
+      5: -26 (20 s), -20 (20.1 s), -26 (20 s)                                 -> -23.0"""
+    seqs = {1: [(-23, 20.0)], 2: [(-33, 20.0)], 3: [(-36, 10.0), (-23, 60.0), (-36, 10.0)],
+            4: [(-72, 10.0), (-36, 10.0), (-23, 60.0), (-36, 10.0), (-72, 10.0)], 5: [(-26, 20.0), (-20, 20.1), (-26, 20.0)]}
+    want = {1: -23.0, 2: -33.0, 3: -23.0, 4: -23.0, 5: -23.0}
+    parts, n0 = [], 0
+    for lvl, dur in seqs[case]:
+        n = int(round(dur * fs))
+        t = (np.arange(n) + n0) / fs
+        parts.append(10.0 ** (lvl / 20.0) * np.sin(2 * np.pi * 1000.0 * t))
+        n0 += n
+    mono = np.concatenate(parts).astype(np.float32)
+    return np.stack([mono, mono], axis=1), want[case]
