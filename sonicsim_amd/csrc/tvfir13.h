@@ -368,8 +368,15 @@ template <class Env> SS_HD void xspec13_body(Env& env, const float* x, int64_t T
     }
     if (m >= M) return;              // (there is no zero spectrum any more: the render kernels' descriptors return zeros)
     Lds13 l; l.base = env.lds();
-    load_consts13(env, l, consts);
     const int wave = tid >> 6, lane = tid & 63;
+    const int k2 = lane >> 3, n4 = lane & 7;
+    // this thread's 22 twiddles straight from the (L2-resident) table into registers: a workgroup forms ONE spectrum, so staging the
+    // 36 KB table through LDS (nine load + store rounds and a barrier) only adds latency in front of the transform (round 3)
+    c32 tw1[8], tw2v[7], tw3v[7];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) tw1[k] = consts[TW1P_13 + k * 512 + tid];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) { tw2v[k - 1] = consts[TW2_13 + (k - 1) * 64 + lane]; tw3v[k - 1] = consts[TW3_13 + (k - 1) * 8 + n4]; }
     c32* Pv = l.priv(wave);
     c32 v[8];
 #pragma unroll
@@ -378,23 +385,22 @@ template <class Env> SS_HD void xspec13_body(Env& env, const float* x, int64_t T
     dft8f<false>(v);
     c32* C = l.cross(0);
 #pragma unroll
-    for (int k = 0; k < 8; ++k) C[k * 512 + tid] = cmul(v[k], l.tw1p()[k * 512 + tid]);
+    for (int k = 0; k < 8; ++k) C[k * 512 + tid] = cmul(v[k], tw1[k]);
     env.barrier();
 #pragma unroll
     for (int n = 0; n < 8; ++n) v[n] = C[wave * 512 + n * 64 + lane];
     dft8f<false>(v);
     Pv[lane] = v[0];
 #pragma unroll
-    for (int k = 1; k < 8; ++k) Pv[k * 72 + lane] = cmul(v[k], l.tw2()[(k - 1) * 64 + lane]);
+    for (int k = 1; k < 8; ++k) Pv[k * 72 + lane] = cmul(v[k], tw2v[k - 1]);
     env.wave_sync();
-    const int k2 = lane >> 3, n4 = lane & 7;
 #pragma unroll
     for (int n = 0; n < 8; ++n) v[n] = Pv[k2 * 72 + n * 8 + n4];
     dft8f<false>(v);
     env.wave_sync();
     Pv[(k2 * 8) * 9 + n4] = v[0];
 #pragma unroll
-    for (int k = 1; k < 8; ++k) Pv[(k2 * 8 + k) * 9 + n4] = cmul(v[k], l.tw3()[(k - 1) * 8 + n4]);
+    for (int k = 1; k < 8; ++k) Pv[(k2 * 8 + k) * 9 + n4] = cmul(v[k], tw3v[k - 1]);
     env.wave_sync();
 #pragma unroll
     for (int n = 0; n < 8; ++n) v[n] = Pv[lane * 9 + n];
