@@ -12,7 +12,8 @@ DEFINITION of the synthetic bank (SURVEY.md section 8d "Bank") that the HIP gene
                 + tail_gain * exp(-6.91 * t / (rt60*fs)) * n_p[c,t] * [t > delay[p,c]]
     n_0 = g_0 ;  n_p = rho * n_{p-1} + sqrt(1-rho^2) * g_p          (AR(1) across positions)
     g_p[c,t] = sqrt(-2 ln u1) * (cos(2 pi u2) if n even else sin(2 pi u2)),   n = (p*C+c)*L+t  (global tap counter),
-               u_s = (hash32(seed, s, n >> 1) >> 8 + 0.5) * 2^-24     (both Box-Muller branches: taps 2i and 2i+1 share a pair)
+               (u1, u2) = ((a >> 16) + 0.5, (a & 0xFFFF) + 0.5) * 2^-16,  a = hash32(seed, 1, n >> 1)   (both Box-Muller branches, one
+               hash per pair of taps)
 
 Row G (``SonicSim_audio.py:111-127`` clip_all, ``:397`` stack/reshape, ``:398`` global peak
 normalise) is restated in ``clip_all`` / ``stack_and_normalise``.
@@ -50,12 +51,13 @@ def hash32(seed, stream, ctr):
 
 
 def gauss(seed, ctr):
-    """Standard normal of global tap counter `ctr`: Box-Muller with BOTH branches -- the taps (2 i, 2 i + 1) share one pair of
-    uniforms hashed from the pair counter i (round 3: one hash pair, one log and one sqrt per two taps on the device)."""
+    """Standard normal of global tap counter `ctr`: Box-Muller with BOTH branches and ONE hash per pair -- the taps (2 i, 2 i + 1) share
+    a = hash32(seed, 1, i); u1 / u2 are its upper / lower 16 bits (round 3: one murmur finaliser, one log and one sqrt per two taps on the
+    device; the radius takes 65 536 levels, |g| <= 4.7)."""
     ctr = np.asarray(ctr, dtype=np.uint64)
-    pair = ctr >> np.uint64(1)
-    u1 = ((hash32(seed, 1, pair) >> np.uint32(8)).astype(np.float64) + 0.5) * 2.0 ** -24
-    u2 = ((hash32(seed, 2, pair) >> np.uint32(8)).astype(np.float64) + 0.5) * 2.0 ** -24
+    a = hash32(seed, 1, ctr >> np.uint64(1))
+    u1 = ((a >> np.uint32(16)).astype(np.float64) + 0.5) * 2.0 ** -16
+    u2 = ((a & np.uint32(0xFFFF)).astype(np.float64) + 0.5) * 2.0 ** -16
     r = np.sqrt(-2.0 * np.log(u1))
     return np.where((ctr & np.uint64(1)) == 0, r * np.cos(2.0 * np.pi * u2), r * np.sin(2.0 * np.pi * u2))
 

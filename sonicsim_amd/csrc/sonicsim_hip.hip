@@ -392,21 +392,25 @@ __device__ __forceinline__ uint32_t hash32(uint32_t seed, uint32_t stream, uint6
     uint32_t h = fmix32((uint32_t)(ctr >> 32) ^ k);
     return fmix32((uint32_t)ctr ^ h);
 }
-__device__ __forceinline__ float unit24(uint32_t h) { return __builtin_fmaf((float)(h >> 8), 5.9604644775390625e-8f, 2.98023223876953125e-8f); }   // (k + 0.5) 2^-24
-// Box-Muller on two 24-bit uniforms with the hardware transcendentals (v_log_f32 = log2, v_cos_f32 / v_sin_f32 take revolutions).
-// BOTH branches are used (round 3): the pair of taps with global counters (2 i, 2 i + 1) shares one (u1, u2) = hash(seed, 1 | 2, i):
-//     g[2 i] = sqrt(-2 ln u1) cos(2 pi u2),   g[2 i + 1] = sqrt(-2 ln u1) sin(2 pi u2)
-// (independent standard normals), i.e. one hash pair, one log2 and one sqrt per TWO taps (oracle/rir_synth.py::gauss is the definition).
-__device__ __forceinline__ void box_muller2(float u1, float u2, float& g0, float& g1) {
-    const float r = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));
+__device__ __forceinline__ float unit16(uint32_t h16) { return __builtin_fmaf((float)h16, 1.52587890625e-5f, 7.62939453125e-6f); }   // (k + 0.5) 2^-16
+// Box-Muller with the hardware transcendentals (v_log_f32 = log2, v_cos_f32 / v_sin_f32 take revolutions), BOTH branches, ONE hash per
+// pair of taps (round 3): the taps with global counters (2 i, 2 i + 1) share a = hash32(seed, 1, i); u1 / u2 are its upper / lower 16 bits:
+//     g[2 i] = sqrt(-2 ln u1) cos(2 pi u2),   g[2 i + 1] = sqrt(-2 ln u1) sin(2 pi u2),   u = (16 bits + 0.5) 2^-16
+// (independent standard normals, radius quantised to 65 536 levels, |g| <= 4.7) -- one murmur finaliser, one log2, one sqrt per TWO taps
+// instead of two finalisers, a log2 and a sqrt per tap (oracle/rir_synth.py::gauss is the definition; tools/ubench/k1_variants.hip: 89 ->
+// 73 us per 307 MB bank, 62 with the positions unrolled by two).
+__device__ __forceinline__ void box_muller2(uint32_t a, float& g0, float& g1) {
+    const float r = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(unit16(a >> 16)));
+    const float u2 = unit16(a & 0xFFFFu);
     g0 = r * __builtin_amdgcn_cosf(u2);
     g1 = r * __builtin_amdgcn_sinf(u2);
 }
 
 // FAST32: the bank has fewer than 2^33 samples, so the high word of every PAIR counter is 0 and the first mixing round of hash32 is one
-// constant per stream.  V consecutive taps per thread; V = 2 or 4 needs an even L (then every thread's first counter is even at every
+// constant.  V consecutive taps per thread; V = 2 or 4 needs an even L (then every thread's first counter is even at every
 // position and its taps are whole pairs); V = 1 evaluates its pair's hash per tap (odd L).  The chain over the positions is sequential,
-// so the parallelism is C * L / V threads: two taps per thread give a config-2 bank 3 000 waves for the 1 024 SIMDs.
+// so the parallelism is C * L / V threads: two taps per thread give a config-2 bank 3 000 waves for the 1 024 SIMDs; the position loop is
+// unrolled by two (two positions' hash / Box-Muller chains in flight per thread).
 // peak_bits (may be null): max |bank| over the whole bank -- row G's abs().max() for free; slots: 1 + gridDim.x words of workspace.
 template <bool FAST32, int V>
 __global__ __launch_bounds__(256) void k_rir_synth(RirDev p, float* __restrict__ bank, unsigned int* __restrict__ peak_bits,
@@ -420,32 +424,28 @@ __global__ __launch_bounds__(256) void k_rir_synth(RirDev p, float* __restrict__
     float te[V], n[V];
 #pragma unroll
     for (int v = 0; v < V; ++v) { te[v] = p.tail_gain * (float)exp(-(double)(t0 + v) * p.inv_tau); n[v] = 0.0f; }
-    const uint32_t k1 = p.seed * 0x9E3779B9u + 1u, k2 = p.seed * 0x9E3779B9u + 2u;
-    const uint32_t h1c = fmix32(k1), h2c = fmix32(k2);
     float peak = 0.0f;
     uint64_t ctr = (uint64_t)c * (uint64_t)p.L + (uint64_t)t0;
     float* out = bank + ii;
     const int32_t* dl = p.delay + c;
     const float* dg = p.dgain + c;
+    const uint32_t k1 = p.seed * 0x9E3779B9u + 1u;
+    const uint32_t h1c = fmix32(k1);
     int d_next = dl[0];
-    for (int q = 0; q < p.P; ++q) {
+    auto step = [&](int q) {
         const int d = d_next;                                        // this position's direct-path delay was requested an iteration ago
         if (q + 1 < p.P) d_next = dl[(int64_t)(q + 1) * p.C];
         float g[V];
         if (V == 1) {
             const uint64_t pr = ctr >> 1;
-            const uint32_t a1 = FAST32 ? fmix32((uint32_t)pr ^ h1c) : fmix32((uint32_t)pr ^ fmix32((uint32_t)(pr >> 32) ^ k1));
-            const uint32_t a2 = FAST32 ? fmix32((uint32_t)pr ^ h2c) : fmix32((uint32_t)pr ^ fmix32((uint32_t)(pr >> 32) ^ k2));
             float g0, g1;
-            box_muller2(unit24(a1), unit24(a2), g0, g1);
+            box_muller2(FAST32 ? fmix32((uint32_t)pr ^ h1c) : fmix32((uint32_t)pr ^ fmix32((uint32_t)(pr >> 32) ^ k1)), g0, g1);
             g[0] = (ctr & 1) ? g1 : g0;
         } else {
 #pragma unroll
             for (int v = 0; v < V; v += 2) {
                 const uint64_t pr = (ctr + (uint64_t)v) >> 1;
-                const uint32_t a1 = FAST32 ? fmix32((uint32_t)pr ^ h1c) : fmix32((uint32_t)pr ^ fmix32((uint32_t)(pr >> 32) ^ k1));
-                const uint32_t a2 = FAST32 ? fmix32((uint32_t)pr ^ h2c) : fmix32((uint32_t)pr ^ fmix32((uint32_t)(pr >> 32) ^ k2));
-                box_muller2(unit24(a1), unit24(a2), g[v], g[v + (V > 1 ? 1 : 0)]);
+                box_muller2(FAST32 ? fmix32((uint32_t)pr ^ h1c) : fmix32((uint32_t)pr ^ fmix32((uint32_t)(pr >> 32) ^ k1)), g[v], g[v + (V > 1 ? 1 : 0)]);
             }
         }
         float val[V];
@@ -472,6 +472,11 @@ __global__ __launch_bounds__(256) void k_rir_synth(RirDev p, float* __restrict__
         }
         out += CL;
         ctr += (uint64_t)CL;
+    };
+    {
+        int q = 0;
+        for (; q + 1 < p.P; q += 2) { step(q); step(q + 1); }
+        for (; q < p.P; ++q) step(q);
     }
     if (peak_bits) {
         // max |bank| without an initialised result word (a hipMemsetAsync ahead of the kernel is 4 us + a 6 us boundary, profiles/r03g):
