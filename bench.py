@@ -3,7 +3,8 @@
 
     python bench.py --gpus N --steps K --warmup W                      (BASELINE.json config 2, the headline)
     python bench.py --config cfg4 --steps 64                           (config 4: K full SonicSet scenes per rank + gather of the mixes)
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    (N > 1: either plain `python bench.py --gpus N` -- it starts the ranks itself -- or python -m torch.distributed.run --nnodes=1
+     --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
 
 Default: a "step" is one pass of the hot path over one scene-source: BASELINE.json config 2 = single moving source, 8-mic
 circular array, 60 s @ 16 kHz (T=960000), 200 trajectory points, 48000-tap RIRs -> ss_convolve_moving_seg_f32 (rows I+V fused)
@@ -12,15 +13,21 @@ resident in HBM before the timed region; outputs stay in HBM.  Scenes shard acro
 scaling: every rank renders its own scene each step); for N > 1 every 5th render of every rank travels to rank 0 (RCCL grouped
 point-to-point over xGMI) WHILE the following renders run -- config 4's ratio of one gathered (C, T) payload per five renders.
 
-Rank 0 prints ONE JSON line (contract in the task statement).  `value` is the sustained rate (an untimed pre-roll brings the
-clocks up first); `value_cold` is the same K steps timed straight after the W warm-up steps of a fresh process.  Extra objects:
-  roofline     -- algorithmic bytes per launch / average launch duration of the overlap-save kernel, measured live with HIP
-                  events on the kernel's own stream (ss_prof_*).
+Rank 0 prints ONE JSON line (contract in the task statement).  `value` is the sustained rate: after an untimed pre-roll (clock ramp-up) the
+MEDIAN of `--windows` (7) windows, each = W warm-up steps + exactly K timed steps between barrier + synchronize, with no HIP events inside
+(an event pair costs 4-5 us per bracketed launch); every window, the clocks / power around it (amdgpu sysfs) and `value_cold` (the same K
+steps straight after the W warm-up steps of the fresh process) are printed too.  `python bench.py --gpus N` without a launcher starts its N
+ranks itself (torch.distributed.run, one process per GPU) and refuses when the node has fewer GPUs.  Extra objects:
+  roofline     -- algorithmic bytes per launch / mean launch duration of the overlap-save kernel, measured live with HIP events on the
+                  kernel's own stream (ss_prof_*) in event windows interleaved with the value windows; min / median / p90 / max of every
+                  timed launch.
   cpu_baseline -- the oracle's restatement of the reference algorithm (SciPy oaconvolve of EVERY position + gather,
-                  SonicSim_moving.py:86-94) timed on one host core over the WHOLE config (all 200 positions, ~15 s); its output
-                  is what `parity_rel_rms_vs_oracle` compares the timed render with.
-  cpu_baseline_all_cores / cpu_smart -- the same algorithm spread over the host cores (positions are independent), and the
-                  segment-wise reformulation (2 instead of P convolutions per sample) on one core.
+                  SonicSim_moving.py:86-94) timed on one host core: the WHOLE config when that takes <= ~45 s (config 2: all 200
+                  positions, ~13 s; its output is what `parity_rel_rms_vs_oracle` compares the timed render with), else a bounded sample of the
+                  positions scaled to all of them (config 5).
+  cpu_baseline_all_cores / cpu_smart -- the same algorithm spread over the host cores (oracle/allcores.py; its whole-config output is the
+                  parity reference when the single-core leg is a sample), and the segment-wise reformulation (2 instead of P convolutions
+                  per sample) on one core.
 The oracle is used here only as the timed CPU baseline and as the checker.
 """
 import argparse
