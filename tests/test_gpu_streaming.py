@@ -115,6 +115,10 @@ def test_time_sharded_render_on_two_ranks(gpu, config):
         p.start()
     for p in procs:
         p.join(timeout=300)
+    for p in procs:                                   # never leave a stuck rank behind (it would hold the GPU and the rendezvous port)
+        if p.is_alive():
+            p.kill()
+            p.join(timeout=10)
     assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
     tag, rel, shape, cuts = q.get(timeout=10)
     assert tag == "ok" and rel < 2e-6, rel
