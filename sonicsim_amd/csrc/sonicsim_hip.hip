@@ -1864,7 +1864,7 @@ int render(int mode, const float* x, int64_t T, const float* bank, int32_t P, in
     const size_t seg_bytes = 2 * sizeof(int64_t) * (size_t)P;      // [seg_start P x i64][inv_seg P x f64: 1/len(segment k), IEEE double division]
     const size_t blob = seg_bytes + sizeof(Task) * (n0 + n1);
     Pinned* pin;
-    if ((rc = pinned_acquire(c, blob, &pin))) return rc;
+    if ((rc = pinned_acquire(c, (blob + 15) / 16 * 16, &pin))) return rc;      // k_xspec13 stages whole 16-byte units
     memset(pin->host, 0, seg_bytes);
     if (mode == COEF_SEG) {
         memcpy(pin->host, c->seg_start.data(), sizeof(int64_t) * (size_t)P);
@@ -1918,15 +1918,17 @@ int render(int mode, const float* x, int64_t T, const float* bank, int32_t P, in
                 qgroups = !c->dynq ? 0 : ((nwg >= 8 && nwg % 8 == 0) ? 8 : 1);
                 qinit = 0;                                   // every task, the first one included, comes from the queue
             }
-            if (g13 || g14) hipLaunchKernelGGL(k_xspec13, dim3(M + 1), dim3(NT13), 0, stream, dx, T, (const c32*)c->consts13, (c32*)c->ws[WS_XS], M,
-                                               knob("SS_NO_ZFILL") ? (float*)nullptr : dy /* (tuning build: spectra kernel without its zero fill -- results WRONG) */,
-                                               (int64_t)C * T, (g13 || qgroups) ? (int*)c->ws[WS_CNT] : (int*)nullptr, g13 ? 1 : qgroups + 1,
-                                               g13 ? 0 : qinit, xdiv, rs, xspec_stages_plan ? (const uint4*)pin->host : (const uint4*)nullptr,
-                                               xspec_stages_plan ? (uint4*)c->ws[WS_PLAN] : (uint4*)nullptr, xspec_stages_plan ? (int)blob16 : 0,
-                                               dev_plan ? (const int32_t*)c->async_status : (const int32_t*)nullptr);
-            if (xspec_stages_plan) {       // the ring slot may be rewritten once the spectra kernel has consumed it
-                HIPCHK(hipEventRecord(pin->ev, stream));
-                pin->pending = true;
+            if (g13 || g14) {
+                hipLaunchKernelGGL(k_xspec13, dim3(M + 1), dim3(NT13), 0, stream, dx, T, (const c32*)c->consts13, (c32*)c->ws[WS_XS], M,
+                                   knob("SS_NO_ZFILL") ? (float*)nullptr : dy /* (tuning build: spectra kernel without its zero fill -- results WRONG) */,
+                                   (int64_t)C * T, (g13 || qgroups) ? (int*)c->ws[WS_CNT] : (int*)nullptr, g13 ? 1 : qgroups + 1,
+                                   g13 ? 0 : qinit, xdiv, rs, xspec_stages_plan ? (const uint4*)pin->host : (const uint4*)nullptr,
+                                   xspec_stages_plan ? (uint4*)c->ws[WS_PLAN] : (uint4*)nullptr, xspec_stages_plan ? (int)blob16 : 0,
+                                   dev_plan ? (const int32_t*)c->async_status : (const int32_t*)nullptr);
+                if (xspec_stages_plan) {       // the ring slot may be rewritten once the spectra kernel has consumed it
+                    HIPCHK(hipEventRecord(pin->ev, stream));
+                    pin->pending = true;
+                }
             }
             else if (g12) hipLaunchKernelGGL(k_xspec12, dim3(M + 1), dim3(NT12), 0, stream, dx, T, (const c32*)c->consts12, (c32*)c->ws[WS_XS], M,
                                         dy, (int64_t)C * T, (int*)nullptr);

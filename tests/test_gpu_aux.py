@@ -90,9 +90,9 @@ def test_bank_peak_tracked_by_generator_and_deferred_division(gpu):
     x = torch.from_numpy(sc.x).to(gpu)
     idx, w = moving.expand_segments(seg)
     ref = moving.convolve_moving_receiver(sc.x, norm.cpu().numpy(), idx, w)
-    for path in (None, "os2048", "direct"):                                                     # fused into the spectra kernel / generic pre-scaling
-        yd = ops.convolve_moving_seg(x, raw, seg, bank_peak=peak, path=path)
-        assert rel_rms(yd.cpu().numpy(), ref) < 1e-5, path
+    for path in (None, "asm", "os13", "os4096", "os2048", "direct"):                            # fused into the spectra kernel / generic pre-scaling
+        yd = ops.convolve_moving_seg(x, raw, seg, bank_peak=peak, path=path)                     # (round 4: "os13" once ran BOTH spectra kernels --
+        assert rel_rms(yd.cpu().numpy(), ref) < 1e-5, path                                       # a dangling else -- and lost the division)
     with pytest.raises(ValueError):
         ops.convolve_moving_seg(sc.x, raw.cpu().numpy(), seg, bank_peak=peak)
 
