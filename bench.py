@@ -165,6 +165,40 @@ def algorithmic_bytes(T, P, C, L):
     return 4 * P * C * L + 4 * T + 8 * T + 4 * T + 4 * C * T
 
 
+FP32_VECTOR_PEAK_TFLOPS = 157.3   # MI355X fp32 vector (and fp32 MFMA) peak, MI355X_MICROARCH.md
+
+
+def render_flops(seg, P, C, L, block=4096, jmax=4):
+    """Arithmetic of the row-stationary overlap-save render as planned (plan.h row_tasks): per task NP_eff forward transforms of the
+    filter partitions, NP_eff x nj spectrum MACs, nj inverse transforms; a B-point complex transform counted as 5 B log2 B, a complex
+    MAC as 8 flop per bin.  (The reference's own algorithm -- oaconvolve of every position -- costs ~20x more; this is the work the
+    kernel really does.)"""
+    import math
+    import numpy as np
+    start = np.concatenate([[0], np.cumsum(np.asarray(seg, dtype=np.int64))]) if seg is not None else None
+    NP = -(-L // block)
+    fft = 5.0 * block * math.log2(block)
+    mac = 8.0 * block
+    total = 0.0
+    rows = range(P) if start is not None else range(1)
+    for r in rows:
+        if start is not None:
+            a0 = int(start[r - 1 if r > 0 else r]); a2 = int(start[r + 1 if r < P - 1 else r])
+        else:
+            a0, a2 = 0, int(P)                      # (fixed receiver: P carries T)
+        if a2 <= a0:
+            continue
+        j = a0 // block
+        nb = -(-(a2 - j * block) // block)
+        while nb > 0:
+            nj = min(jmax, nb)
+            np_eff = min(NP, j + nj)
+            total += np_eff * fft + np_eff * nj * mac + nj * fft
+            j += nj
+            nb -= nj
+    return total * C
+
+
 # ------------------------------------------------------------------------------------------------ CPU legs (rank 0, N = 1)
 def cpu_baselines(sc, seg, bank_h, budget_s, all_cores=True):
     import numpy as np
@@ -309,7 +343,7 @@ def run_cfg2(args, rank, local_rank, world, dev):
         prewarm_steps += 10
     prof_every = int(os.environ.get("BENCH_PROF_EVERY", "1"))
     nwin = max(1, args.windows)
-    nevw = max(1, int(os.environ.get("BENCH_EVENT_WINDOWS", "4")))
+    nevw = max(1, int(getattr(args, "event_windows", None) or os.environ.get("BENCH_EVENT_WINDOWS", "4")))
     tel.start()
     t_sus0 = time.perf_counter()
     windows, ev_windows = [], []
@@ -351,7 +385,7 @@ def run_cfg2(args, rank, local_rank, world, dev):
     t_sus1 = time.perf_counter()
     # ---- informational A/B in the same process: the static task lists (ss_set_task_queue(0)), one window
     ab_static = None
-    if world == 1 and not os.environ.get("BENCH_NO_AB"):
+    if world == 1 and not os.environ.get("BENCH_NO_AB") and not getattr(args, "no_ab", False):
         ops.set_task_queue(False)
         rec_v, _ = window(False)
         rec_e, _ = window(True)
@@ -381,11 +415,15 @@ def run_cfg2(args, rank, local_rank, world, dev):
     if os.path.exists(pmc):
         try:
             js = json.load(open(pmc))
-            traffic = (js.get("k_os13_asm") or {}).get("hbm_bytes_per_launch")
-            traffic_src = js.get("_source", "profiles/pmc_summary.json (separate rocprofv3 --pmc passes of an earlier run of this command, "
-                                            "not this process)")
+            # counters are per workload: the committed passes ran config 2; another config reports null unless its own passes exist
+            key = "k_os13_asm" if args.config == "cfg2" else f"k_os13_asm@{args.config}"
+            traffic = (js.get(key) or {}).get("hbm_bytes_per_launch")
+            if traffic is not None:
+                traffic_src = js.get("_source", "profiles/pmc_summary.json (separate rocprofv3 --pmc passes of an earlier run of this command, "
+                                                "not this process)")
         except Exception:
             traffic = None
+    flops = render_flops(seg, sc.P, sc.C, sc.L)
     out = {
         "metric": "rendered-audio-sec/sec (8-mic, 200-pt trajectory, 16 kHz)" if args.config == "cfg2" else
                   f"rendered-audio-sec/sec ({sc.C}-ch, {sc.P}-pt trajectory, {sc.fs // 1000} kHz)",
@@ -428,6 +466,13 @@ def run_cfg2(args, rank, local_rank, world, dev):
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                      "kernel": "k_os13_asm (hand-scheduled gfx950 assembly: row-stationary partitioned overlap-save, B=4096, persistent, "
                                "one launch per render)",
+                     "compute": {"flops_per_launch": flops / max(1.0, launches_per_render), "unit": "TFLOP/s",
+                                 "achieved": flops / max(1.0, launches_per_render) / (avg_launch_ms * 1e-3) / 1e12 if avg_launch_ms > 0 else 0.0,
+                                 "peak": FP32_VECTOR_PEAK_TFLOPS,
+                                 "frac": (flops / max(1.0, launches_per_render) / (avg_launch_ms * 1e-3) / 1e12 / FP32_VECTOR_PEAK_TFLOPS) if avg_launch_ms > 0 else 0.0,
+                                 "note": "the bound this kernel lives under (DESIGN.md section 6): the arithmetic of the planned transforms (5 B log2 B per "
+                                         "B-point complex transform, 8 flop per complex MAC) against the fp32 vector peak; an FFT is adds and multiplies, "
+                                         "not FMAs, so ~0.5 is its ceiling"},
                      "algorithmic_bytes_per_render": render_bytes, "launches_per_render": launches_per_render,
                      "algorithmic_bytes_per_launch": bytes_per_launch,
                      "bytes_the_entry_point_touches": render_bytes - 12 * sc.T,       # idx/w (12 T bytes) are implicit in ss_convolve_moving_seg_f32
@@ -507,6 +552,50 @@ def run_scenes(args, rank, local_rank, world, dev):
         return None
     audio_s = pool[0].T / pool[0].fs
     spec = pool[0]
+    # ---- roofline of the scene's dominant kernel (ONE k_os13_asm launch = the 3 moving + 2 static renders), HIP events on its stream, in a
+    #      separate pass of a few scenes after the timed region; byte model of SURVEY.md section 8d
+    from sonicsim_amd import ops
+    nev = min(16, per_rank)
+    run(2, None, 20_000)
+    torch.cuda.synchronize()
+    ops.prof_enable(True, every=1)
+    t0e = time.perf_counter()
+    run(nev, None, 30_000)
+    torch.cuda.synchronize()
+    dt_ev = time.perf_counter() - t0e
+    os_ms, xs_ms = ops.prof_list(0), ops.prof_list(1)
+    ops.prof_enable(False)
+    P_mov = len(pool[0].speakers[0][3]) + 1
+    moving_bytes = algorithmic_bytes(spec.T, P_mov, spec.C, spec.L)
+    static_bytes = 4 * spec.C * spec.L + 4 * spec.T + 4 * spec.C * spec.T
+    stem = 4 * spec.C * spec.T
+    launch_bytes = 3 * moving_bytes + 2 * static_bytes
+    scene_bytes = launch_bytes + 5 * 2 * stem + 4 * stem                  # + loudness (read + write of 5 stems) + mix (read 3, write 1)
+    k1_bytes = 3 * 4 * P_mov * spec.C * spec.L + 2 * 4 * spec.C * spec.L   # the banks K1 writes inside the timed region (config 4 only; not in 8d's model)
+    launches_per_scene = len(os_ms) / max(1, nev)
+    avg_os = sum(os_ms) / max(1, len(os_ms))
+    ach = launch_bytes / max(1.0, launches_per_scene) / (avg_os * 1e-3) / 1e9 if avg_os > 0 else 0.0
+    ms_scene = dt / per_rank * 1e3
+    fl = sum(render_flops(sp_[3], P_mov, spec.C, spec.L) for sp_ in pool[0].speakers) + 2 * render_flops(None, spec.T, spec.C, spec.L)
+    roof = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+            "kernel": "k_os13_asm, ONE persistent launch for the 3 moving + 2 static renders of a scene (ss_convolve_scene_f32)",
+            "algorithmic_bytes_per_launch": launch_bytes / max(1.0, launches_per_scene), "launches_per_scene": launches_per_scene,
+            "avg_launch_ms": avg_os, "launch_ms": dist_stats(os_ms), "xspec_ms": dist_stats(xs_ms),
+            "avg_launch_is": f"mean over the {len(os_ms)} event-timed launches of {nev} scenes rendered after the timed region ({dt_ev / nev * 1e3:.3f} ms per scene "
+                             "with the events)",
+            "compute": {"flops_per_launch": fl, "achieved": fl / (avg_os * 1e-3) / 1e12 if avg_os > 0 else 0.0, "unit": "TFLOP/s", "peak": FP32_VECTOR_PEAK_TFLOPS,
+                        "frac": fl / (avg_os * 1e-3) / 1e12 / FP32_VECTOR_PEAK_TFLOPS if avg_os > 0 else 0.0},
+            "scene": {"algorithmic_bytes_per_scene": scene_bytes,
+                      "bytes_model": "SURVEY.md 8d: 3 x moving render (4PCL + 4T + 8T + 4T + 4CT) + 2 x static render (4CL + 4T + 4CT) + loudness (read + write of 5 "
+                                     "stems) + mix (read 3 stems, write 1)",
+                      "achieved": scene_bytes / (ms_scene * 1e-3) / 1e9, "frac": scene_bytes / (ms_scene * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                      "bank_bytes_written_by_k1_inside_the_timed_region": k1_bytes,
+                      "frac_with_k1_writes": (scene_bytes + k1_bytes) / (ms_scene * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                      "note": "whole-scene figure: every kernel of the scene (K1 x 5, spectra, render, loudness x 4 launches, mix) and the gaps between them "
+                              "against the bytes of the 8d model; K1's 0.92 GB of bank writes are work of config 4's timed region that the model does not count"}}
+    cpu = None
+    if world == 1 and getattr(args, "cpu_seconds", 0) > 0:
+        cpu = cpu_scene_chain(spec, rend, dev, getattr(args, "cfg2_cpu_seconds", None), audio_s)
     return {
         "metric": "scene-sec/sec (full SonicSet sample: 3 moving + 2 static renders + LUFS + mix, 8-mic, 60 s @ 16 kHz)",
         "value": total * audio_s / dt,
@@ -525,7 +614,235 @@ def run_scenes(args, rank, local_rank, world, dev):
                    "renders_per_second": total * 5 / dt, "rendered_audio_sec_per_sec": total * 5 * audio_s / dt},
         "result_checksum": float(res.double().abs().mean().item()) if res is not None else None,
         "lufs_gain_mean": float(run.gains.mean()) if getattr(run, "gains", None) is not None else None,
+        "roofline": roof,
+        "cpu_baseline": cpu,
     }
+
+
+def cpu_scene_chain(spec, rend, dev, moving_seconds, audio_s):
+    """CPU leg of a SonicSet scene (one core): the oracle chain 3 x row V + 2 x row F + 5 x row U + row M on the stems of one scene.
+    The three moving renders have exactly config 2's shapes: their time is 3 x the config-2 single-core measurement of this very run when
+    the headline leg took it (the bounded sample of this leg), else it is measured on 16 positions and scaled.  Loudness = the BS.1770
+    restatement (pyloudnorm is absent, SURVEY 8d asks for the label)."""
+    import numpy as np
+    import torch
+
+    from oracle import loudness as OL
+    from oracle import mix as OM
+    from oracle import moving as O
+    from sonicsim_amd import ops
+    stems = rend.stack.detach().cpu().numpy()                       # the five rendered, not yet normalised stems of the last scene
+    (x, delay, dgain, rt60) = spec.statics[0]
+    h = ops.rir_bank_synth(delay, dgain, spec.L, spec.fs, rt60, 12345, device=dev)[0].cpu().numpy()
+    xh = x.cpu().numpy()
+    O.convolve_fixed_receiver(xh[:16000], h[:, :4000])
+    t0 = time.perf_counter()
+    for _ in range(2):
+        O.convolve_fixed_receiver(xh, h)
+    t_f = time.perf_counter() - t0
+    np.random.seed(1)
+    t0 = time.perf_counter()
+    normed = [OL.get_lufs_norm_audio(np.ascontiguousarray(stems[j].T), spec.fs, tgt, allow_many_channels=True)[0] for j, tgt in enumerate((-17, -17, -17, -24, -29))]
+    t_u = time.perf_counter() - t0
+    spk = np.stack([normed[0].T, normed[1].T])
+    t0 = time.perf_counter()
+    OM.mix(spk, normed[3].T[None], np.asarray([1.5], np.float32), 15.0)
+    t_m = time.perf_counter() - t0
+    if moving_seconds is None:
+        (xm, dl, dg, seg, rt) = spec.speakers[0]
+        Ps = 16
+        bank = ops.rir_bank_synth(dl[:Ps].contiguous(), dg[:Ps].contiguous(), spec.L, spec.fs, rt, 777, device=dev).cpu().numpy()
+        from scipy import signal
+        xmh = xm.cpu().numpy()
+        t0 = time.perf_counter()
+        signal.oaconvolve(xmh[None, None, :], bank, axes=-1)
+        moving_seconds = (time.perf_counter() - t0) * (len(seg) + 1) / Ps
+        how = f"oaconvolve of {Ps} positions scaled to {len(seg) + 1}"
+    else:
+        how = "the config-2 single-core leg of this run (same T, P, C, L)"
+    total = 3 * moving_seconds + t_f + t_u + t_m
+    return {"value": audio_s / total, "unit": "scene-sec/sec", "cores": 1, "kind": "port",
+            "sample": f"one scene on one core: 3 x moving render = 3 x {moving_seconds:.2f} s ({how}) + 2 static renders (scipy fftconvolve, {t_f:.2f} s measured) + "
+                      f"5 loudness normalisations (BS.1770 restatement of pyloudnorm -- pyloudnorm is absent --, {t_u:.2f} s measured) + the 2-speaker + noise mix "
+                      f"({t_m:.2f} s measured) = {total:.1f} s",
+            "seconds_measured": t_f + t_u + t_m, "seconds_per_scene": total}
+
+
+def run_cfg1(args, dev):
+    """BASELINE.json config 1 (plumbing): static source, mono microphone, 1 s @ 16 kHz, 4096-tap RIR -- ss_convolve_fixed_f32 against
+    scipy fftconvolve (the reference's convolve_fixed_receiver, SonicSim_moving.py:47-61)."""
+    import numpy as np
+    import torch
+
+    from oracle import moving as O
+    from sonicsim_amd import ops, synth
+    sc = synth.make_scene("cfg1", scene=0)
+    h = ops.rir_bank_synth(sc.delay, sc.dgain, sc.L, sc.fs, sc.rt60, sc.bank_seed, device=dev)[0]
+    x = torch.from_numpy(sc.x).to(dev)
+    y = torch.empty((sc.C, sc.T), dtype=torch.float32, device=dev)
+    K = 200
+    for _ in range(20):
+        ops.convolve_fixed(x, h, out=y)
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        for _ in range(K):
+            ops.convolve_fixed(x, h, out=y)
+        torch.cuda.synchronize()
+        ts.append((time.perf_counter() - t0) / K)
+    ts.sort()
+    dt = ts[len(ts) // 2]
+    ops.prof_enable(True, every=1)
+    for _ in range(50):
+        ops.convolve_fixed(x, h, out=y)
+    torch.cuda.synchronize()
+    os_ms = ops.prof_list(0)
+    seen = ops.prof_seen(0)
+    ops.prof_enable(False)
+    xh, hh = sc.x, h.cpu().numpy()
+    ref = O.convolve_fixed_receiver(xh, hh)
+    n = 0
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < 2.0:
+        O.convolve_fixed_receiver(xh, hh)
+        n += 1
+    t_cpu = (time.perf_counter() - t0) / n
+    t0 = time.perf_counter()
+    for _ in range(20):
+        yh = ops.convolve_fixed(xh, hh)                    # the reference's own calling convention: NumPy in, NumPy out
+    t_host = (time.perf_counter() - t0) / 20
+    nbytes = 4 * sc.C * sc.L + 4 * sc.T + 4 * sc.C * sc.T
+    audio_s = sc.T / sc.fs
+    lp = seen / 50.0
+    avg = sum(os_ms) / max(1, len(os_ms))
+    return {"metric": "rendered-audio-sec/sec (static source, mono, 16 kHz)", "value": audio_s / dt, "unit": "rendered-audio-sec/sec", "ms_per_step": dt * 1e3,
+            "steps": K, "dtype": "f32",
+            "config": {"workload": "cfg1: single static source, mono microphone, 1 s @ 16000 Hz, 4096-tap RIR (T=16000) -- plumbing case",
+                       "T": sc.T, "P": 1, "C": sc.C, "L": sc.L, "entry_point": "ss_convolve_fixed_f32",
+                       "engine": "geometry 11 (HIP, B = 2048, two parity passes): L <= 4096"},
+            "end_to_end_host": {"ms": t_host * 1e3, "value": audio_s / t_host, "note": "NumPy in, NumPy out through ops.convolve_fixed (staging rings, one synchronisation)"},
+            "roofline": {"bound": "hbm", "achieved": nbytes / (avg * 1e-3 * lp) / 1e9 if avg > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": nbytes / (avg * 1e-3 * lp) / 1e9 / HBM_PEAK_GBS if avg > 0 else 0.0, "traffic": None,
+                         "algorithmic_bytes_per_render": nbytes, "launches_per_render": lp, "avg_launch_ms": avg,
+                         "note": "144 KB of algorithmic bytes and 8 tasks: launch-latency bound by construction (a plumbing case, 8 workgroups on a 256-CU chip)"},
+            "cpu_baseline": {"value": audio_s / t_cpu, "unit": "rendered-audio-sec/sec", "cores": 1, "kind": "port",
+                             "sample": f"the whole config: scipy fftconvolve as in convolve_fixed_receiver (SonicSim_moving.py:47-61), {n} repetitions in 2 s, "
+                                       f"{t_cpu * 1e3:.3f} ms each", "seconds_measured": t_cpu},
+            "parity_rel_rms_vs_oracle": float(np.sqrt(np.mean((y.cpu().numpy().astype(np.float64) - ref) ** 2)) / np.sqrt(np.mean(ref.astype(np.float64) ** 2))),
+            "parity_host_path_same_bits": bool(np.array_equal(yh, y.cpu().numpy()))}
+
+
+def run_hostpath(args, dev):
+    """The path SonicSet.py:77 really takes: CPU tensors / NumPy arrays in, a CPU array out (SonicSim_moving.py:122-125), through the
+    drop-in's own entry point -- PCIe inclusive, never `value`."""
+    import numpy as np
+    import torch
+
+    from sonicsim_amd import SonicSim_moving as M
+    from sonicsim_amd import ops, synth
+    sc = synth.make_scene("cfg2", scene=0)
+    seg = synth.scene_segments(sc, 0)
+    dbank = ops.rir_bank_synth(sc.delay, sc.dgain, sc.L, sc.fs, sc.rt60, sc.bank_seed, device=dev)
+    ops.peak_normalize_(dbank)
+    dx = torch.from_numpy(sc.x).to(dev)
+    want = ops.convolve_moving_seg(dx, dbank, seg)
+    bank_t = dbank.cpu()
+    bank = bank_t.numpy()
+    want_h = want.cpu().numpy()
+    # PCIe reference: pinned DMA of the same bytes (torch plumbing)
+    pb = bank_t.pin_memory()
+    py = torch.empty_like(want, device="cpu").pin_memory()
+    dst = torch.empty_like(dbank)
+
+    def best(fn, n=5):
+        fn()
+        ts = []
+        for _ in range(n):
+            t0 = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t0)
+        return min(ts), sorted(ts)[len(ts) // 2]
+
+    t_up = best(lambda: (dst.copy_(pb, non_blocking=True), torch.cuda.synchronize()))[0]
+    t_dn = best(lambda: (py.copy_(want, non_blocking=True), torch.cuda.synchronize()))[0]
+    del pb, dst
+    src = torch.from_numpy(sc.x)[None]
+    ir = bank_t[:, None]
+
+    def dropin():
+        np.random.seed(4000)
+        return M.interpolate_moving_audio(src, ir, sc.positions)
+
+    y1 = dropin()
+    same = bool(np.array_equal(y1.numpy(), want_h))
+    t_full = best(dropin)
+    st_full = ops.host_path_stats()
+    t_xy = best(lambda: ops.convolve_moving_seg(sc.x, dbank, seg, host_io=True))
+    y2 = ops.convolve_moving_seg(sc.x, dbank, seg, host_io=True)
+    po = ops.pinned_empty(want_h.shape)
+    px = ops.pinned_empty(sc.x.shape)
+    px[:] = sc.x
+    t_xyp = best(lambda: ops.convolve_moving_seg(px, dbank, seg, host_io=True, out=po))
+    audio_s = sc.T / sc.fs
+    nb = bank.nbytes + sc.x.nbytes
+    return {"workload": "cfg2 shapes through SonicSim_moving.interpolate_moving_audio(CPU tensor (1, T), CPU tensor (P, 1, C, L), positions) -> CPU tensor (C, T): "
+                        "what SonicSet.py:77-79 calls",
+            "ms": t_full[0] * 1e3, "ms_median": t_full[1] * 1e3, "rendered_audio_sec_per_sec": audio_s / t_full[0],
+            "same_bits_as_the_resident_render": same and bool(np.array_equal(y2, want_h)),
+            "bytes_up": st_full["bytes_up"], "bytes_down": st_full["bytes_down"], "bank_chunks": st_full["chunks"], "copy_threads": st_full["threads"],
+            "pcie_pinned_dma_reference": {"up_ms": t_up * 1e3, "up_GBs": bank.nbytes / t_up / 1e9, "down_ms": t_dn * 1e3,
+                                          "note": "one pinned hipMemcpyAsync of the bank / of y (torch), the link's ceiling for these bytes"},
+            "x_pcie_time_of_the_bytes_moved": t_full[0] / (t_up * nb / bank.nbytes),
+            "resident_bank_host_x_y": {"ms": t_xy[0] * 1e3, "ms_median": t_xy[1] * 1e3, "ms_pinned_arrays": t_xyp[0] * 1e3,
+                                       "note": "SS_FLAG_BANK_DEVICE: the bank stays in HBM, x (3.84 MB) goes up and y (30.7 MB) comes back per render"},
+            "how": "hostpipe.h: the bank crosses PCIe through a ring of pinned slots filled by 4 host threads, in chunks of whole positions; chunk k is "
+                   "rendered (static task lists) while chunk k + 1 is on the wire; finished stretches of y travel back at once"}
+
+
+def secondary_legs(args, rank, local_rank, dev, primary):
+    """The other BASELINE.json configurations in the same driver-run line (N = 1): cfg5 (largest single-GPU render), cfg4's per-GPU
+    share (64 full scenes), cfg1 (plumbing), and the host-pointer path of cfg2.  Each leg is a dict with its own config.workload,
+    ms_per_step, roofline and cpu_baseline; a leg that fails reports its error instead of taking the headline down."""
+    import copy
+    import gc
+    import traceback
+
+    import torch
+    legs = {}
+
+    def guarded(name, fn):
+        t0 = time.perf_counter()
+        try:
+            legs[name] = fn()
+        except Exception as e:                                   # noqa: BLE001 -- the headline line must survive
+            legs[name] = {"error": repr(e), "traceback": traceback.format_exc()[-1500:]}
+        if isinstance(legs[name], dict):
+            legs[name]["leg_seconds"] = time.perf_counter() - t0
+        gc.collect()
+        torch.cuda.empty_cache()
+
+    def cfg5():
+        a = copy.copy(args)
+        a.config, a.steps, a.warmup, a.windows, a.event_windows, a.no_ab = "cfg5", 10, 2, 3, 2, True
+        a.cpu_seconds = min(args.cpu_seconds, 12.0)
+        o = run_cfg2(a, rank, local_rank, 1, dev)
+        for k in ("clocks",):
+            o.pop(k, None)
+        return o
+
+    def cfg4():
+        a = copy.copy(args)
+        a.config, a.steps, a.warmup = "cfg4", 64, 2
+        cb = (primary.get("cpu_baseline") or {})
+        a.cfg2_cpu_seconds = cb.get("seconds_measured") if "whole config" in str(cb.get("sample", "")) else None
+        return run_scenes(a, rank, local_rank, 1, dev)
+
+    guarded("cfg5", cfg5)
+    guarded("cfg4_per_gpu_share", cfg4)
+    guarded("cfg1", lambda: run_cfg1(args, dev))
+    guarded("cfg2_end_to_end_host", lambda: run_hostpath(args, dev))
+    return legs
 
 
 def self_launch(args, torch):
@@ -562,7 +879,13 @@ def main():
     ap.add_argument("--gather-every", type=int, default=5)
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--windows", type=int, default=7, help="timed K-step windows of the sustained section (value = the median window)")
+    ap.add_argument("--event-windows", type=int, default=None)
+    ap.add_argument("--no-secondary", action="store_true", help="default run (cfg2, N = 1) without the legs for cfg5 / cfg4 / cfg1 / the host-pointer path")
+    ap.add_argument("--lib", default=os.environ.get("BENCH_LIB"), help="measurement tools: another build of the library (tuning / A-B variants)")
     args = ap.parse_args()
+    if args.lib:
+        from sonicsim_amd import _lib
+        _lib.use_library(args.lib)
     if args.cpu_positions == 0:
         args.cpu_seconds = 0
 
@@ -612,6 +935,8 @@ def main():
             raise SystemExit(f"{world} ranks share {len(set(ids))} GPUs: one process per GPU is required")
     ops.init(local_dev)
     out = run_scenes(args, rank, local_rank, world, dev) if args.config in ("cfg3", "cfg4") else run_cfg2(args, rank, local_rank, world, dev)
+    if rank == 0 and world == 1 and args.config == "cfg2" and not args.no_secondary and not os.environ.get("BENCH_NO_SECONDARY"):
+        out["secondary"] = secondary_legs(args, rank, local_rank, dev, out)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -45,6 +45,7 @@ extern "C" {
 #define SS_FLAG_META_DEVICE 0x1000u /* ss_rir_bank_synth*_f32 with SS_FLAG_DEVICE_PTR: SsRirParams.delay / .dgain are DEVICE pointers (no staging copy) */
 #define SS_FLAG_RESULT_DEVICE 0x2000u /* ss_lufs_norm_batch_f32 with SS_FLAG_DEVICE_PTR: `result` is a DEVICE array of 4 * S doubles; the call only enqueues work (no synchronisation) */
 #define SS_FLAG_KEEP_SPEAKERS 0x4000u /* ss_mix_f32: do not write the scaled interferers back into `speakers` (read-only input; the mix is the only output) */
+#define SS_FLAG_BANK_DEVICE 0x8000u /* render entry points WITHOUT SS_FLAG_DEVICE_PTR: `rirs` alone is a DEVICE pointer (a resident bank rendered for a host dry signal into a host array) */
 #define SS_FLAG_ASYNC_PLAN 0x800u /* ss_convolve_moving_f32 with device pointers: plan the explicit schedule on the device (no host synchronisation) */
 
 int ss_version(void);
@@ -90,6 +91,23 @@ int ss_plan_status_last(int32_t* out_of_range, int64_t* where, int32_t* too_irre
  * with less run-to-run spread, but a workgroup that cannot be placed still owns its list: 4 of 256 compute units held = +62 % kernel
  * time.  Same output bits either way. */
 int ss_set_task_queue(int dynamic);
+
+/* ---- host-pointer mode (flags without SS_FLAG_DEVICE_PTR): the path SonicSim_moving.py:122-125 really takes -- NumPy in, NumPy out.
+ * The library moves the caller's arrays through a ring of pinned staging slots filled by a few host threads while the DMA engine drains
+ * them (a single memcpy stream cannot keep the PCIe link busy), and for the implicit schedule on the assembly engine it cuts the bank into
+ * chunks of whole trajectory positions: the rows of chunk k are rendered while chunk k + 1 is on the wire, and every stretch of the output
+ * that no later chunk touches travels back at once.  Same bits as the device-pointer render.  Buffers the caller pinned itself
+ * (ss_host_alloc, hipHostMalloc, hipHostRegister) are recognised and moved by DMA directly, without the staging copy.
+ * ss_set_host_pipe: copy threads (0 = keep; default 4: more only contend for the memory system, profiles/r04a), bytes per staging slot (default 16 MiB, 6 up + 4 down),
+ * bytes per bank chunk (default 24 MiB, at most 16 chunks) -- current device.
+ * ss_host_path_stats: {seconds inside the last host-pointer render call, bytes up, bytes down, bank chunks, direct (pinned) transfers,
+ * copy threads} of the current device. */
+int ss_set_host_pipe(int threads, int64_t slot_bytes, int64_t chunk_bytes);
+int ss_host_path_stats(double* out, int32_t n);
+/* pinned host memory the DMA engines address directly (hipHostMalloc / hipHostFree): a caller that renders into such a buffer skips the
+ * staging copy of host-pointer mode */
+int ss_host_alloc(void** out, int64_t bytes);
+int ss_host_free(void* p);
 
 /* ---- rows I+V fused: SonicSim_moving.py:42-45 + :63-96 ---------------------------------------
  * Fast path of interpolate_moving_audio (SonicSim_moving.py:98-125).  The host keeps only the O(P)

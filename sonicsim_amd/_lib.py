@@ -10,7 +10,7 @@ import ctypes
 import os
 
 PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("SS_LIB") or os.path.join(PKG, "lib", "libsonicsim_hip.so")   # SS_LIB: A/B builds (tools/)
+LIB_PATH = os.path.join(PKG, "lib", "libsonicsim_hip.so")     # the product reads no environment switch; A/B builds: use_library()
 
 FLAG_DEVICE_PTR = 0x1
 FLAG_PATH_OS = 0x10
@@ -24,6 +24,7 @@ FLAG_ASYNC_PLAN = 0x800
 FLAG_META_DEVICE = 0x1000
 FLAG_RESULT_DEVICE = 0x2000
 FLAG_KEEP_SPEAKERS = 0x4000
+FLAG_BANK_DEVICE = 0x8000
 
 SS_EINVAL, SS_EHIP, SS_ENOMEM, SS_ENODEV = -1, -2, -3, -4
 
@@ -49,6 +50,10 @@ _SIGS = {
                                               ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32,
                                               ctypes.c_void_p]),
     "ss_set_task_queue": (ctypes.c_int, [ctypes.c_int]),
+    "ss_set_host_pipe": (ctypes.c_int, [ctypes.c_int, ctypes.c_int64, ctypes.c_int64]),
+    "ss_host_path_stats": (ctypes.c_int, [c_f64p, ctypes.c_int32]),
+    "ss_host_alloc": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int64]),
+    "ss_host_free": (ctypes.c_int, [ctypes.c_void_p]),
     "ss_async_status": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "ss_plan_status_last": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "ss_convolve_moving_seg_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32,
@@ -99,6 +104,16 @@ _SIGS = {
 
 EXPORTS = tuple(_SIGS)
 _lib = None
+
+
+def use_library(path: str):
+    """Measurement tools only (tools/, bench.py --lib): load another build of the library -- the tuning build with its experiment
+    switches, an A/B variant -- instead of the product's.  Must be called before the first load(); an explicit call, never an
+    environment variable, so that nothing in a user's environment can swap the library under the drop-in modules."""
+    global LIB_PATH
+    if _lib is not None:
+        raise RuntimeError("use_library() must be called before the library is first loaded")
+    LIB_PATH = os.path.abspath(path)
 
 
 def load():

@@ -79,8 +79,6 @@ def build_asm(force: bool = False, verbose: bool = False) -> str:
 
 def build(force: bool = False, verbose: bool = False, extra=None, out=None) -> str:
     """extra / out: A/B builds with additional hipcc flags into another file (tools/); the product build uses neither."""
-    if out is None and os.environ.get("SS_LIB"):
-        return os.environ["SS_LIB"]
     if out is None:
         build_asm(force=force, verbose=verbose)
     if out is None and not force and not is_stale():
@@ -101,7 +99,7 @@ TUNING_OUT = os.path.join(PKG, "lib", "libsonicsim_hip_tuning.so")
 def build_tuning(force: bool = False, verbose: bool = False) -> str:
     """The library the tools/ scripts use: the product source with -DSS_TUNING_KNOBS, i.e. with the environment switches of the
     experiments (SS_HSACO, SS_TRACE_FILE, SS_DYNQ, SS_OS_GEOM, SS_HOP_RS, ...).  The product library reads no environment variable
-    (one test switch aside).  Select it with SS_LIB=<this path>."""
+    (one test switch aside).  Select it with `_lib.use_library(path)` (bench.py: --lib / BENCH_LIB)."""
     build_asm(force=force, verbose=verbose)
     srcs = [SRC] + [os.path.join(os.path.dirname(SRC), f) for f in os.listdir(os.path.dirname(SRC)) if f.endswith(".h")]
     if not force and os.path.exists(TUNING_OUT) and all(os.path.getmtime(f) <= os.path.getmtime(TUNING_OUT) for f in srcs):

@@ -1,0 +1,288 @@
+// hostpipe.h -- pipelined staging between the caller's HOST buffers and HBM (round 4).
+//
+// The reference hands NumPy arrays in and takes a NumPy array back (SonicSim_moving.py:122-125: convolve_moving_receiver(
+// source1_audio.numpy()[0], np.array(ir1_list).squeeze(1), ...) -> torch.from_numpy(...)): a 307 MB bank of pageable memory per
+// moving source at config 2.  Rounds 1-3 pushed it through hipMemcpyAsync on pageable pointers and a synchronous device-to-host
+// copy.  This file is the replacement:
+//   * a ring of pinned slots, filled by a small pool of host threads (one memcpy stream cannot keep a PCIe Gen5 x16 link busy) while
+//     the DMA engine drains the slots already filled -- `up` stream, host-to-device;
+//   * the mirror image for results -- `down` stream, device-to-host into pinned slots, copied out to the caller's array while the
+//     next piece is in flight;
+//   * buffers the caller has already pinned (hipHostMalloc / hipHostRegister) are recognised and moved by DMA directly.
+// The render code (render() in sonicsim_hip.hip) hangs its launches on events of these streams, so the render of bank chunk i runs
+// while chunk i + 1 is on the wire and finished stretches of the output travel back while later chunks are still coming in.
+// Included by sonicsim_hip.hip only (needs its fail() / HIPCHK).
+#pragma once
+// (<condition_variable>, <deque>, <thread> are included at the top of sonicsim_hip.hip: this file sits inside its anonymous namespace)
+
+struct CopyPool {
+    std::vector<std::thread> th;
+    std::mutex mu;
+    std::condition_variable cv, cvd;
+    struct Seg { char* d; const char* s; size_t n; };
+    std::vector<Seg> segs;      // the current job: independent (dst, src, bytes) pieces, cut into `parts` slices over all bytes
+    size_t total = 0;
+    int parts = 1, gen = 0, left = 0;
+    bool stop = false;
+
+    ~CopyPool() { shutdown(); }
+    void shutdown() {
+        {
+            std::lock_guard<std::mutex> l(mu);
+            stop = true;
+        }
+        cv.notify_all();
+        for (auto& t : th) t.join();
+        th.clear();
+        stop = false;
+    }
+    void resize(int n) {      // n = threads in all, the caller's included
+        if (n < 1) n = 1;
+        if ((int)th.size() == n - 1) return;
+        shutdown();
+        const int g0 = gen;     // a new worker must not mistake jobs that ran before it existed for a pending one
+        for (int i = 0; i < n - 1; ++i) th.emplace_back([this, i, g0] { run(i + 1, g0); });
+    }
+    // slice i of the concatenation of all pieces
+    void slice(int i) {
+        const size_t per = ((total + (size_t)parts - 1) / (size_t)parts + 63) & ~(size_t)63;
+        size_t a = per * (size_t)i, b = a + per < total ? a + per : total;
+        size_t base = 0;
+        for (const Seg& sg : segs) {
+            if (a >= b) break;
+            const size_t lo = a > base ? a - base : 0;
+            if (lo < sg.n) {
+                const size_t hi = b - base < sg.n ? b - base : sg.n;
+                memcpy(sg.d + lo, sg.s + lo, hi - lo);
+                a = base + hi;
+            }
+            base += sg.n;
+        }
+    }
+    void run(int i, int seen) {
+        for (;;) {
+            std::unique_lock<std::mutex> l(mu);
+            cv.wait(l, [&] { return stop || gen != seen; });
+            if (stop) return;
+            seen = gen;
+            l.unlock();
+            slice(i);
+            l.lock();
+            if (--left == 0) cvd.notify_one();
+        }
+    }
+    void go() {
+        total = 0;
+        for (const Seg& sg : segs) total += sg.n;
+        parts = (int)th.size() + 1;
+        if (total < ((size_t)256 << 10) || th.empty()) {      // small jobs: the wake-up costs more than it saves
+            parts = 1;
+            slice(0);
+            return;
+        }
+        {
+            std::lock_guard<std::mutex> l(mu);
+            left = (int)th.size();
+            ++gen;
+        }
+        cv.notify_all();
+        slice(0);
+        std::unique_lock<std::mutex> l(mu);
+        cvd.wait(l, [&] { return left == 0; });
+    }
+    void copy(void* d, const void* s, size_t n) {
+        segs.assign(1, Seg{(char*)d, (const char*)s, n});
+        go();
+    }
+};
+
+struct HostPipe {
+    static constexpr int NUP = 6, NDOWN = 4;
+    size_t slot_bytes = (size_t)16 << 20;
+    size_t chunk_bytes = (size_t)24 << 20;   // render() cuts a host bank into chunks of about this size (whole trajectory positions)
+    int threads = 0;                    // 0 = choose at first use
+    hipStream_t up = nullptr, down = nullptr;
+    char* ups[NUP] = {};
+    hipEvent_t upev[NUP] = {};
+    bool upbusy[NUP] = {};
+    int upnext = 0;
+    char* dns[NDOWN] = {};
+    hipEvent_t dnev[NDOWN] = {};
+    int dnnext = 0;
+    std::vector<hipEvent_t> evpool;     // chunk-ready / chunk-done events (no timing)
+    size_t evused = 0;
+    CopyPool pool;
+    struct Pending {                    // a device-to-host piece on the wire: slot -> rows of the caller's array
+        int slot;
+        char* dst;                      // first row's destination
+        size_t row_bytes, dst_pitch;
+        int rows;
+    };
+    std::deque<Pending> pending;
+    // statistics of the last host-pointer render (ss_host_path_stats)
+    double st_bytes_up = 0, st_bytes_down = 0, st_seconds = 0;
+    int st_chunks = 0, st_direct = 0;
+};
+
+static int hp_ensure(HostPipe& h) {
+    if (h.up) return SS_OK;
+    HIPCHK(hipStreamCreateWithFlags(&h.up, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&h.down, hipStreamNonBlocking));
+    for (int i = 0; i < HostPipe::NUP; ++i) {
+        HIPCHK(hipHostMalloc((void**)&h.ups[i], h.slot_bytes, hipHostMallocDefault));
+        HIPCHK(hipEventCreateWithFlags(&h.upev[i], hipEventDisableTiming));
+    }
+    for (int i = 0; i < HostPipe::NDOWN; ++i) {
+        HIPCHK(hipHostMalloc((void**)&h.dns[i], h.slot_bytes, hipHostMallocDefault));
+        HIPCHK(hipEventCreateWithFlags(&h.dnev[i], hipEventDisableTiming));
+    }
+    if (h.threads <= 0) {
+        const unsigned hw = std::thread::hardware_concurrency();
+        h.threads = hw >= 8 ? 4 : (hw >= 2 ? 2 : 1);      // measured (profiles/r04a): 4 memcpy threads feed a Gen5 x16 link, more only contend
+    }
+    h.pool.resize(h.threads);
+    return SS_OK;
+}
+
+static void hp_destroy(HostPipe& h) {
+    h.pool.shutdown();
+    for (int i = 0; i < HostPipe::NUP; ++i) {
+        if (h.ups[i]) hipHostFree(h.ups[i]);
+        if (h.upev[i]) hipEventDestroy(h.upev[i]);
+        h.ups[i] = nullptr; h.upev[i] = nullptr; h.upbusy[i] = false;
+    }
+    for (int i = 0; i < HostPipe::NDOWN; ++i) {
+        if (h.dns[i]) hipHostFree(h.dns[i]);
+        if (h.dnev[i]) hipEventDestroy(h.dnev[i]);
+        h.dns[i] = nullptr; h.dnev[i] = nullptr;
+    }
+    for (hipEvent_t e : h.evpool) hipEventDestroy(e);
+    h.evpool.clear();
+    if (h.up) hipStreamDestroy(h.up);
+    if (h.down) hipStreamDestroy(h.down);
+    h.up = h.down = nullptr;
+}
+
+static int hp_event(HostPipe& h, hipEvent_t* out) {
+    if (h.evused == h.evpool.size()) {
+        hipEvent_t e;
+        HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        h.evpool.push_back(e);
+    }
+    *out = h.evpool[h.evused++];
+    return SS_OK;
+}
+
+// true when the DMA engines can address `p` directly (hipHostMalloc / hipHostRegister memory)
+static bool hp_is_pinned(const void* p) {
+    hipPointerAttribute_t at;
+    memset(&at, 0, sizeof(at));
+    const hipError_t e = hipPointerGetAttributes(&at, p);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();        // an ordinary malloc'ed pointer: not an error for us
+        return false;
+    }
+    return at.type == hipMemoryTypeHost;
+}
+
+// copies finished device-to-host pieces out of their slots; all = false: only those whose DMA has already completed
+static int hp_drain(HostPipe& h, bool all) {
+    while (!h.pending.empty()) {
+        HostPipe::Pending& p = h.pending.front();
+        if (!all) {
+            const hipError_t q = hipEventQuery(h.dnev[p.slot]);
+            if (q == hipErrorNotReady) { (void)hipGetLastError(); return SS_OK; }
+            if (q != hipSuccess) return fail(SS_EHIP, "hipEventQuery failed: %s", hipGetErrorString(q));
+        } else {
+            HIPCHK(hipEventSynchronize(h.dnev[p.slot]));
+        }
+        h.pool.segs.clear();
+        for (int r = 0; r < p.rows; ++r)
+            h.pool.segs.push_back(CopyPool::Seg{p.dst + (size_t)r * p.dst_pitch, h.dns[p.slot] + (size_t)r * p.row_bytes, p.row_bytes});
+        h.pool.go();
+        h.pending.pop_front();
+    }
+    return SS_OK;
+}
+
+// host [src, src + bytes) -> device dst on the `up` stream, in pieces of one slot.  Returns when everything is on its way (the last
+// pieces may still be in flight: the caller records an event on h.up).  `progress(done_bytes)` is called after every piece has been
+// ENQUEUED (render() hangs the launch of a bank chunk on it); finished device-to-host pieces are copied out in between.
+template <class F> static int hp_upload(HostPipe& h, void* dst, const void* src, size_t bytes, F progress) {
+    h.st_bytes_up += (double)bytes;
+    const bool direct = hp_is_pinned(src);
+    if (direct) ++h.st_direct;
+    for (size_t off = 0; off < bytes; off += h.slot_bytes) {
+        const size_t n = bytes - off < h.slot_bytes ? bytes - off : h.slot_bytes;
+        if (direct) {
+            HIPCHK(hipMemcpyAsync((char*)dst + off, (const char*)src + off, n, hipMemcpyHostToDevice, h.up));
+        } else {
+            const int q = h.upnext;
+            h.upnext = (h.upnext + 1) % HostPipe::NUP;
+            if (h.upbusy[q]) {
+                HIPCHK(hipEventSynchronize(h.upev[q]));
+                h.upbusy[q] = false;
+            }
+            h.pool.copy(h.ups[q], (const char*)src + off, n);
+            HIPCHK(hipMemcpyAsync((char*)dst + off, h.ups[q], n, hipMemcpyHostToDevice, h.up));
+            HIPCHK(hipEventRecord(h.upev[q], h.up));
+            h.upbusy[q] = true;
+        }
+        int rc = progress(off + n);
+        if (rc) return rc;
+        if ((rc = hp_drain(h, false))) return rc;
+    }
+    return SS_OK;
+}
+static int hp_upload(HostPipe& h, void* dst, const void* src, size_t bytes) {
+    return hp_upload(h, dst, src, bytes, [](size_t) { return (int)SS_OK; });
+}
+
+// device rows -> host rows on the `down` stream: `rows` rows of row_bytes, src_pitch apart on the device, dst_pitch apart on the host
+// (rows == 1: a flat copy).  The caller has made h.down wait for the producer.  Pageable destinations go through the slot ring and are
+// completed by hp_drain.
+static int hp_download(HostPipe& h, void* dst, size_t dst_pitch, const void* src, size_t src_pitch, size_t row_bytes, int rows) {
+    h.st_bytes_down += (double)row_bytes * rows;
+    if (row_bytes == 0 || rows == 0) return SS_OK;
+    if (hp_is_pinned(dst)) {
+        ++h.st_direct;
+        if (rows == 1) HIPCHK(hipMemcpyAsync(dst, src, row_bytes, hipMemcpyDeviceToHost, h.down));
+        else HIPCHK(hipMemcpy2DAsync(dst, dst_pitch, src, src_pitch, row_bytes, (size_t)rows, hipMemcpyDeviceToHost, h.down));
+        return SS_OK;
+    }
+    // pieces of at most 4 MiB (and one slot): whole rows cut along their length.  Small pieces keep the tail short -- the last piece's copy
+    // into the caller's (often freshly allocated, not yet faulted-in) array is all that is left once the last DMA has landed
+    const size_t piece = h.slot_bytes < ((size_t)4 << 20) ? h.slot_bytes : ((size_t)4 << 20);
+    size_t w = piece / (size_t)rows & ~(size_t)63;
+    if (w == 0) return fail(SS_EINVAL, "too many rows for the staging slots");
+    for (size_t off = 0; off < row_bytes; off += w) {
+        const size_t n = row_bytes - off < w ? row_bytes - off : w;
+        if ((int)h.pending.size() == HostPipe::NDOWN) {      // the slot we are about to reuse is the oldest pending one
+            HostPipe::Pending& p = h.pending.front();
+            HIPCHK(hipEventSynchronize(h.dnev[p.slot]));
+            h.pool.segs.clear();
+            for (int r = 0; r < p.rows; ++r)
+                h.pool.segs.push_back(CopyPool::Seg{p.dst + (size_t)r * p.dst_pitch, h.dns[p.slot] + (size_t)r * p.row_bytes, p.row_bytes});
+            h.pool.go();
+            h.pending.pop_front();
+        }
+        const int q = h.dnnext;
+        h.dnnext = (h.dnnext + 1) % HostPipe::NDOWN;
+        if (rows == 1) HIPCHK(hipMemcpyAsync(h.dns[q], (const char*)src + off, n, hipMemcpyDeviceToHost, h.down));
+        else HIPCHK(hipMemcpy2DAsync(h.dns[q], n, (const char*)src + off, src_pitch, n, (size_t)rows, hipMemcpyDeviceToHost, h.down));
+        HIPCHK(hipEventRecord(h.dnev[q], h.down));
+        h.pending.push_back(HostPipe::Pending{q, (char*)dst + off, n, dst_pitch, rows});
+    }
+    return SS_OK;
+}
+
+// everything on both streams done, every pending piece copied out
+static int hp_finish(HostPipe& h) {
+    int rc = hp_drain(h, true);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(h.down));
+    HIPCHK(hipStreamSynchronize(h.up));
+    for (bool& b : h.upbusy) b = false;
+    h.evused = 0;
+    return SS_OK;
+}

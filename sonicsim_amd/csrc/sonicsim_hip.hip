@@ -4,6 +4,10 @@
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
 
+#include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <thread>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -1454,6 +1458,8 @@ int fail(int code, const char* fmt, ...) {
         if (e_ != hipSuccess) return fail(e_ == hipErrorOutOfMemory ? SS_ENOMEM : SS_EHIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
     } while (0)
 
+#include "hostpipe.h"
+
 enum WsSlot { WS_XS, WS_PLAN, WS_BMIN, WS_BMAX, WS_X, WS_BANK, WS_IDX, WS_W, WS_Y, WS_SCR, WS_SCR2, WS_FILT, WS_META, WS_CNT, WS_LUFS, WS_RES, WS_KWP, WS_KWT, WS_GW, WS_DPLAN, WS_DTASKS, WS_K1, WS_COUNT };
 
 struct Pinned {
@@ -1514,6 +1520,8 @@ struct Ctx {
     int num_cu = 0;
     bool last_dev_planned = false;        // the last render() on this device planned its schedule on the device (ss_plan_status_last is about it)
     int32_t* async_status = nullptr;      // device: {code, where} latched by k_plan_explicit (SS_FLAG_ASYNC_PLAN), read by ss_async_status
+    HostPipe pipe;          // host-pointer mode: pinned staging rings, copy streams, copy threads (hostpipe.h)
+    std::vector<Task> chunk_tmp;
     std::mutex mu;          // one lock per device context: entry points are re-entrant per device (one host thread per GPU works)
 };
 
@@ -1712,30 +1720,44 @@ int render(int mode, const float* x, int64_t T, const float* bank, int32_t P, in
     if ((rc = stream_enter(c, stream))) return rc;
     const bool dev = (flags & SS_FLAG_DEVICE_PTR) != 0;
 
-    // ---- staging for host-pointer mode
+    // ---- staging for host-pointer mode (hostpipe.h): x (and idx / w) go up first through the pinned ring; the bank follows further
+    //      down, behind the spectra kernel -- in chunks interleaved with the render launches where the engine allows it
+    const bool bank_dev = dev || (flags & SS_FLAG_BANK_DEVICE) != 0;
     const float* dx = x;
     const float* dbank = bank;
     const int64_t* didx = idx;
     const float* dw = w;
     float* dy = y;
     const size_t bank_bytes = sizeof(float) * (size_t)P * C * L;
+    HostPipe& hp = c->pipe;
+    const auto host_t0 = std::chrono::steady_clock::now();
     if (!dev) {
+        if ((rc = hp_ensure(hp))) return rc;
+        hp.pending.clear();
+        hp.evused = 0;
+        hp.st_bytes_up = hp.st_bytes_down = hp.st_seconds = 0;
+        hp.st_chunks = hp.st_direct = 0;
         if ((rc = ws_ensure(c, WS_X, sizeof(float) * T))) return rc;
-        if ((rc = ws_ensure(c, WS_BANK, bank_bytes))) return rc;
+        if (!bank_dev && (rc = ws_ensure(c, WS_BANK, bank_bytes))) return rc;
         if ((rc = ws_ensure(c, WS_Y, sizeof(float) * (size_t)C * T))) return rc;
-        HIPCHK(hipMemcpyAsync(c->ws[WS_X], x, sizeof(float) * T, hipMemcpyHostToDevice, stream));
-        HIPCHK(hipMemcpyAsync(c->ws[WS_BANK], bank, bank_bytes, hipMemcpyHostToDevice, stream));
-        dx = (const float*)c->ws[WS_X];
-        dbank = (const float*)c->ws[WS_BANK];
-        dy = (float*)c->ws[WS_Y];
         if (mode == COEF_EXPLICIT) {
             if ((rc = ws_ensure(c, WS_IDX, sizeof(int64_t) * T))) return rc;
             if ((rc = ws_ensure(c, WS_W, sizeof(float) * T))) return rc;
-            HIPCHK(hipMemcpyAsync(c->ws[WS_IDX], idx, sizeof(int64_t) * T, hipMemcpyHostToDevice, stream));
-            HIPCHK(hipMemcpyAsync(c->ws[WS_W], w, sizeof(float) * T, hipMemcpyHostToDevice, stream));
+        }
+        if ((rc = hp_upload(hp, c->ws[WS_X], x, sizeof(float) * T))) return rc;
+        dx = (const float*)c->ws[WS_X];
+        if (!bank_dev) dbank = (const float*)c->ws[WS_BANK];
+        dy = (float*)c->ws[WS_Y];
+        if (mode == COEF_EXPLICIT) {
+            if ((rc = hp_upload(hp, c->ws[WS_IDX], idx, sizeof(int64_t) * T))) return rc;
+            if ((rc = hp_upload(hp, c->ws[WS_W], w, sizeof(float) * T))) return rc;
             didx = (const int64_t*)c->ws[WS_IDX];
             dw = (const float*)c->ws[WS_W];
         }
+        hipEvent_t e_in;
+        if ((rc = hp_event(hp, &e_in))) return rc;
+        HIPCHK(hipEventRecord(e_in, hp.up));
+        HIPCHK(hipStreamWaitEvent(stream, e_in, 0));
     }
 
     // ---- engine choice
@@ -1833,16 +1855,46 @@ int render(int mode, const float* x, int64_t T, const float* bank, int32_t P, in
     }
     const bool fast_plan = g12 && mode == COEF_SEG;        // single-launch geometries, implicit schedule: O(P*C) direct planner
     int32_t qmain = 0;                                     // dynamic queues: tasks in the per-XCD part of the list (0 = all)
+    // host-pointer mode, assembly engine, implicit schedule: the bank travels in `nchunk` chunks of whole positions and the rows of
+    // chunk k are rendered (one launch per chunk, static task lists) while chunk k + 1 is on the wire; the stretch of the output that
+    // no later chunk touches travels back at once.  Every row is still one task and y is accumulated with the same two commutative
+    // additions per sample onto zeros: same bits as the one-launch render.
+    int nchunk = 1;
+    if (!dev && !bank_dev && g14 && fast_plan) {
+        nchunk = (int)std::min<size_t>(16, bank_bytes / hp.chunk_bytes);
+        if (nchunk > P / 2) nchunk = P / 2;
+        if (nchunk < 2) nchunk = 1;
+    }
+    const bool chunked = nchunk > 1;
+    if (chunked && (rc = load_mod13(c, false))) return rc;
+    std::vector<int32_t> chunk_off;
     if (dev_plan) {
     } else if (fast_plan) {
         // XCD-aware task order for the persistent assembly kernel (workgroup b -> XCD b % 8 takes tasks b, b + nwg, ...)
         static const int plan_groups = knob("SS_PLAN_GROUPS") ? atoi(knob("SS_PLAN_GROUPS")) : 8;
         static const int plan_snake = knob("SS_PLAN_SNAKE") ? atoi(knob("SS_PLAN_SNAKE")) : 1;
         static const int plan_tail = knob("SS_PLAN_TAIL") ? atoi(knob("SS_PLAN_TAIL")) : 12;      // % of a range's tasks that go to the shared tail queue
-        const bool two_level = g14 && c->dynq && plan_groups == 8;
+        const bool two_level = g14 && c->dynq && plan_groups == 8 && !chunked;
         plan_seg_lpt(c->seg_start, P, C, BB, JM, NPart, c->plan.tasks[0], c->plan_scratch, (g14 && plan_groups > 1 && plan_groups <= 64) ? plan_groups : 1,
                      (plan_snake && !two_level) ? c->num_cu : 0, rs, two_level ? plan_tail : 0, &qmain);
         c->plan.tasks[1].clear();
+        if (chunked) {      // stable counting sort of the list by the chunk of the task's row (the LPT / XCD order survives inside a chunk)
+            std::vector<Task>& tk = c->plan.tasks[0];
+            chunk_off.assign((size_t)nchunk + 1, 0);
+            auto chunk_of = [&](int row) {
+                int k = (int)(((int64_t)row * nchunk + nchunk - 1) / P);          // smallest k with floor(P k / nchunk) ... refined below
+                if (k > nchunk - 1) k = nchunk - 1;
+                while (k > 0 && (int)((int64_t)P * k / nchunk) > row) --k;
+                while (k + 1 < nchunk && (int)((int64_t)P * (k + 1) / nchunk) <= row) ++k;
+                return k;
+            };
+            for (const Task& t : tk) chunk_off[(size_t)chunk_of(t.row) + 1]++;
+            for (int k = 0; k < nchunk; ++k) chunk_off[(size_t)k + 1] += chunk_off[(size_t)k];
+            c->chunk_tmp.resize(tk.size());
+            std::vector<int32_t> at(chunk_off.begin(), chunk_off.end() - 1);
+            for (const Task& t : tk) c->chunk_tmp[(size_t)at[(size_t)chunk_of(t.row)]++] = t;
+            tk.swap(c->chunk_tmp);
+        }
     } else {
         if (mode == COEF_SEG) seg_minmax(c->seg_start, T, c->bmin, c->bmax);
         if (mode == COEF_FIXED) build_plan_fixed(T, C, use_os ? BB : DTILE, use_os ? JM : 1, c->plan);
@@ -1937,6 +1989,67 @@ int render(int mode, const float* x, int64_t T, const float* bank, int32_t P, in
         HIPCHK(hipGetLastError());
     }
     const Task* dtasks = (const Task*)(plan_base + seg_bytes);
+    if (chunked) {
+        const size_t pos_bytes = sizeof(float) * (size_t)C * L;      // one trajectory position of the bank
+        int64_t done = 0;
+        int k = 0;                                                   // next chunk to launch
+        auto launch_ready = [&](size_t up_bytes) -> int {            // every chunk whose last byte is on its way: launch behind the transfer
+            int rc2;
+            while (k < nchunk) {
+                const int r0 = (int)((int64_t)P * k / nchunk), r1 = (int)((int64_t)P * (k + 1) / nchunk);
+                if (pos_bytes * (size_t)r1 > up_bytes) break;
+                (void)r0;
+                hipEvent_t e_up;
+                if ((rc2 = hp_event(hp, &e_up))) return rc2;
+                HIPCHK(hipEventRecord(e_up, hp.up));
+                HIPCHK(hipStreamWaitEvent(stream, e_up, 0));
+                const int32_t nt = chunk_off[(size_t)k + 1] - chunk_off[(size_t)k];
+                if (nt > 0) {
+                    ProfScope ps(c, stream, 0);
+                    Os13AsmArgs a;
+                    memset(&a, 0, sizeof(a));
+                    a.bank = dbank; a.Xs = prm.Xs; a.tasks = dtasks + chunk_off[(size_t)k];
+                    a.seg_start = plan_base;
+                    a.inv_seg = plan_base + sizeof(int64_t) * (size_t)P;
+                    a.y = dy; a.T = T; a.P = P; a.C = C; a.L = L; a.NP = NPart; a.M = M;
+                    a.ntasks = nt; a.mode = mode; a.nwg = nt < c->num_cu ? nt : c->num_cu;
+                    a.consts = c->consts14; a.counter = nullptr;
+                    a.qgroups = 0;
+                    a.rs = rs;
+                    size_t asz = sizeof(a);
+                    void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &asz, HIP_LAUNCH_PARAM_END};
+                    HIPCHK(hipModuleLaunchKernel(c->fn13, (unsigned)a.nwg, 1, 1, NT13, 1, 1, 0, stream, nullptr, cfg));
+                }
+                // samples before the segment that ends at row r1 - 1 have both their rows in chunks <= k: they are final
+                const int64_t fin = k == nchunk - 1 ? T : c->seg_start[(size_t)(r1 - 1)];
+                if (fin > done) {
+                    hipEvent_t e_done;
+                    if ((rc2 = hp_event(hp, &e_done))) return rc2;
+                    HIPCHK(hipEventRecord(e_done, stream));
+                    HIPCHK(hipStreamWaitEvent(hp.down, e_done, 0));
+                    if ((rc2 = hp_download(hp, y + done, sizeof(float) * (size_t)T, dy + done, sizeof(float) * (size_t)T, sizeof(float) * (size_t)(fin - done), C)))
+                        return rc2;
+                    done = fin;
+                }
+                ++hp.st_chunks;
+                ++k;
+            }
+            return SS_OK;
+        };
+        if ((rc = hp_upload(hp, c->ws[WS_BANK], bank, bank_bytes, launch_ready))) return rc;
+        if ((rc = hp_finish(hp))) return rc;
+        HIPCHK(hipStreamSynchronize(stream));
+        hp.st_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - host_t0).count();
+        return SS_OK;
+    }
+    if (!dev && !bank_dev) {       // the whole bank behind the spectra kernel, pipelined through the pinned ring
+        if ((rc = hp_upload(hp, c->ws[WS_BANK], bank, bank_bytes))) return rc;
+        hipEvent_t e_up;
+        if ((rc = hp_event(hp, &e_up))) return rc;
+        HIPCHK(hipEventRecord(e_up, hp.up));
+        HIPCHK(hipStreamWaitEvent(stream, e_up, 0));
+        hp.st_chunks = 1;
+    }
     for (int parity = 0; parity < 2; ++parity) {
         size_t nt = parity ? n1 : n0;
         if (dev_plan) nt = parity ? 0 : (size_t)c->num_cu;      // the count lives in the list's header: every CU gets a workgroup
@@ -2011,8 +2124,14 @@ int render(int mode, const float* x, int64_t T, const float* bank, int32_t P, in
     HIPCHK(hipGetLastError());
 
     if (!dev) {
-        HIPCHK(hipMemcpyAsync(y, dy, sizeof(float) * (size_t)C * T, hipMemcpyDeviceToHost, stream));
+        hipEvent_t e_done;
+        if ((rc = hp_event(hp, &e_done))) return rc;
+        HIPCHK(hipEventRecord(e_done, stream));
+        HIPCHK(hipStreamWaitEvent(hp.down, e_done, 0));
+        if ((rc = hp_download(hp, y, 0, dy, 0, sizeof(float) * (size_t)C * T, 1))) return rc;
+        if ((rc = hp_finish(hp))) return rc;
         HIPCHK(hipStreamSynchronize(stream));
+        hp.st_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - host_t0).count();
     }
     return SS_OK;
 }
@@ -2183,6 +2302,7 @@ int ss_shutdown(void) {
         if (c->consts14) hipFree(c->consts14);
         if (c->mod13) hipModuleUnload(c->mod13);
         if (c->mod13q) hipModuleUnload(c->mod13q);
+        hp_destroy(c->pipe);
         for (int i = 0; i < WS_COUNT; ++i) if (c->ws[i]) hipFree(c->ws[i]);
         if (c->async_status) hipFree(c->async_status);
         for (auto& p : c->ring) { if (p.host) hipHostFree(p.host); if (p.ev) hipEventDestroy(p.ev); }
@@ -2197,6 +2317,56 @@ int ss_shutdown(void) {
 int ss_convolve_moving_f32(const float* x, int64_t T, const float* rirs, int32_t P, int32_t C, int32_t L, const int64_t* idx,
                            const float* w, float* y, uint32_t flags, void* stream) {
     return render(COEF_EXPLICIT, x, T, rirs, P, C, L, nullptr, idx, w, y, flags, stream);
+}
+
+int ss_set_host_pipe(int threads, int64_t slot_bytes, int64_t chunk_bytes) {
+    Ctx* c;
+    int rc = get_ctx(&c);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lock(c->mu);
+    HostPipe& h = c->pipe;
+    if (threads > 256 || (slot_bytes > 0 && (slot_bytes < (1 << 16) || slot_bytes > ((int64_t)1 << 30))) || (chunk_bytes > 0 && chunk_bytes < (1 << 20)))
+        return fail(SS_EINVAL, "ss_set_host_pipe: threads <= 256, 64 KiB <= slot_bytes <= 1 GiB, chunk_bytes >= 1 MiB (0 / negative = keep)");
+    if (slot_bytes > 0 && (size_t)slot_bytes != h.slot_bytes) {
+        if (h.up) {
+            HIPCHK(hipStreamSynchronize(h.up));
+            HIPCHK(hipStreamSynchronize(h.down));
+        }
+        hp_destroy(h);
+        h.slot_bytes = (size_t)slot_bytes;
+    }
+    if (chunk_bytes > 0) h.chunk_bytes = (size_t)chunk_bytes;
+    if (threads > 0) {
+        h.threads = threads;
+        if (h.up) h.pool.resize(threads);
+    }
+    return SS_OK;
+}
+
+int ss_host_path_stats(double* out, int32_t n) {
+    if (!out || n < 1) return fail(SS_EINVAL, "ss_host_path_stats: out is NULL");
+    Ctx* c;
+    int rc = get_ctx(&c);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lock(c->mu);
+    const HostPipe& h = c->pipe;
+    const double v[6] = {h.st_seconds, h.st_bytes_up, h.st_bytes_down, (double)h.st_chunks, (double)h.st_direct, (double)h.threads};
+    for (int i = 0; i < n && i < 6; ++i) out[i] = v[i];
+    return SS_OK;
+}
+
+int ss_host_alloc(void** out, int64_t bytes) {
+    if (!out || bytes < 1) return fail(SS_EINVAL, "ss_host_alloc: bad argument");
+    Ctx* c;
+    int rc = get_ctx(&c);      // (selects / initialises the device the allocation is mapped for)
+    if (rc) return rc;
+    HIPCHK(hipHostMalloc(out, (size_t)bytes, hipHostMallocDefault));
+    return SS_OK;
+}
+
+int ss_host_free(void* p) {
+    if (p) HIPCHK(hipHostFree(p));
+    return SS_OK;
 }
 
 int ss_set_task_queue(int dynamic) {

@@ -91,6 +91,52 @@ def init(device: int = -1):
     _lib.check(_lib.load().ss_init(int(device)))
 
 
+def _host_out(out, C, T):
+    """Host output (C, T): a fresh pageable array, or the caller's C-contiguous float32 array (e.g. pinned_empty((C, T)))."""
+    if out is None:
+        return np.empty((C, T), dtype=np.float32)
+    if not (isinstance(out, np.ndarray) and out.dtype == np.float32 and out.shape == (C, T) and out.flags.c_contiguous and out.flags.writeable):
+        raise ValueError("out must be a writeable C-contiguous float32 ndarray of shape (C, T)")
+    return out
+
+
+class _PinnedBuf:
+    """pinned (page-locked, DMA-addressable) host memory from ss_host_alloc, freed with the last array that views it"""
+
+    def __init__(self, nbytes):
+        p = ctypes.c_void_p()
+        _lib.check(_lib.load().ss_host_alloc(ctypes.byref(p), int(nbytes)))
+        self.ptr, self.nbytes = p.value, int(nbytes)
+
+    def __del__(self):
+        try:
+            _lib.load().ss_host_free(ctypes.c_void_p(self.ptr))
+        except Exception:
+            pass
+
+
+def pinned_empty(shape, dtype=np.float32):
+    """np.empty in pinned host memory: host-pointer renders move such arrays by DMA directly (no staging copy)."""
+    dt = np.dtype(dtype)
+    n = int(np.prod(shape)) * dt.itemsize
+    buf = _PinnedBuf(max(n, 1))
+    raw = (ctypes.c_char * max(n, 1)).from_address(buf.ptr)
+    raw._owner = buf                      # the array's base keeps `raw`, `raw` keeps the allocation
+    return np.frombuffer(raw, dtype=dt, count=int(np.prod(shape))).reshape(shape)
+
+
+def set_host_pipe(threads=0, slot_bytes=0, chunk_bytes=0):
+    """Host-pointer mode tuning on the current device (0 = keep): copy threads, bytes per pinned staging slot, bytes per bank chunk."""
+    _lib.check(_lib.load().ss_set_host_pipe(int(threads), int(slot_bytes), int(chunk_bytes)))
+
+
+def host_path_stats():
+    """{seconds, bytes_up, bytes_down, chunks, direct_transfers, threads} of the last host-pointer render on the current device."""
+    v = (ctypes.c_double * 6)()
+    _lib.check(_lib.load().ss_host_path_stats(v, 6))
+    return {"seconds": v[0], "bytes_up": v[1], "bytes_down": v[2], "chunks": int(v[3]), "direct_transfers": int(v[4]), "threads": int(v[5])}
+
+
 def _out_ct(out, C, T, dev):
     """Device output (C, T): a fresh tensor, or the caller's contiguous float32 view (e.g. one slot of a stem stack)."""
     import torch
@@ -151,7 +197,7 @@ def convolve_moving(x, rirs, idx, w, path=None, out=None, validate=True):
     _check_moving_shapes(x, rirs, idx, w)
     P, C, L = rirs.shape
     T = x.shape[0]
-    y = np.empty((C, T), dtype=np.float32)
+    y = _host_out(out, C, T)
     _lib.check(lib.ss_convolve_moving_f32(_ptr(x), T, _ptr(rirs), P, C, L, _ptr(idx), _ptr(w), _ptr(y), flags, None))
     return y
 
@@ -189,13 +235,34 @@ def _check_moving_shapes(x, rirs, idx, w):
 
 
 @_restores_device
-def convolve_moving_seg(x, rirs, seg_len, path=None, out=None, bank_peak=None):
+def convolve_moving_seg(x, rirs, seg_len, path=None, out=None, bank_peak=None, host_io=False):
     """Rows I+V fused (SonicSim_moving.py:42-45 + :63-96): seg_len (P-1,) host ints, sum == T.
+    Host arrays in -> host array out (the reference's own calling convention, SonicSim_moving.py:122-125): the library pipelines the
+    bank through pinned staging slots in chunks and renders each chunk while the next one is on the wire; ``out`` may then be a
+    C-contiguous float32 (C, T) ndarray -- one from ``pinned_empty`` receives the result by DMA without the staging copy.
+    host_io=True with a DEVICE bank and a host x: only x and y cross PCIe (``out`` as above).
     bank_peak (device tensors only): a one-element float32 device tensor -- render with ``rirs / bank_peak``, i.e. the global
     peak normalisation of SonicSim_audio.py:398 deferred into the render (``rir_bank_synth(..., return_peak=True)``)."""
     lib = _lib.load()
     flags = PATHS[path]
     seg = np.ascontiguousarray(np.asarray(seg_len).astype(np.int64))
+    if host_io and _is_dev(rirs) and not _is_dev(x):
+        # a RESIDENT bank rendered for a host dry signal into a host array (SS_FLAG_BANK_DEVICE): only x (4T bytes) and y (4CT bytes)
+        # cross PCIe, through the library's pinned staging rings
+        import torch
+        if bank_peak is not None:
+            raise ValueError("bank_peak needs device tensors throughout")
+        rirs = _dev32(rirs, "rirs")
+        x = _np32(x, "x")
+        if x.ndim != 1 or rirs.ndim != 3 or seg.shape != (rirs.shape[0] - 1,):
+            raise ValueError("shapes: x (T,), rirs (P,C,L), seg_len (P-1,)")
+        P, C, L = rirs.shape
+        T = x.shape[0]
+        y = _host_out(out, C, T)
+        _set_device(rirs)
+        _lib.check(lib.ss_convolve_moving_seg_f32(_ptr(x), T, _ptr(rirs), P, C, L, _ptr(seg), _ptr(y), flags | _lib.FLAG_BANK_DEVICE,
+                                                  _stream_ptr(rirs)))
+        return y
     if _is_dev(x) or _is_dev(rirs):
         import torch
         dev = x.device if _is_dev(x) else rirs.device
@@ -224,7 +291,7 @@ def convolve_moving_seg(x, rirs, seg_len, path=None, out=None, bank_peak=None):
         raise ValueError("shapes: x (T,), rirs (P,C,L), seg_len (P-1,)")
     P, C, L = rirs.shape
     T = x.shape[0]
-    y = np.empty((C, T), dtype=np.float32)
+    y = _host_out(out, C, T)
     _lib.check(lib.ss_convolve_moving_seg_f32(_ptr(x), T, _ptr(rirs), P, C, L, _ptr(seg), _ptr(y), flags, None))
     return y
 
@@ -307,7 +374,7 @@ def convolve_fixed(x, h, path=None, out=None):
         raise ValueError("rirs must be (num_channels, ir_length)")
     C, L = h.shape
     T = x.shape[0]
-    y = np.empty((C, T), dtype=np.float32)
+    y = _host_out(out, C, T)
     _lib.check(lib.ss_convolve_fixed_f32(_ptr(x), T, _ptr(h), C, L, _ptr(y), flags, None))
     return y
 

@@ -1,0 +1,129 @@
+"""Host-pointer mode (round 4): the calling convention of the reference itself -- NumPy in, NumPy out (SonicSim_moving.py:122-125).
+The bank travels through the pinned staging ring in chunks of whole positions, chunk k is rendered while chunk k + 1 is on the wire
+and finished stretches of the output travel back at once.  Every variant must give the SAME BITS as the device-pointer render."""
+import numpy as np
+import pytest
+import torch
+
+from util import golden_inputs
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def small_chunks():
+    from sonicsim_amd import ops
+    ops.init(0)
+    ops.set_host_pipe(chunk_bytes=1 << 20)           # 1 MiB chunks: a 6 MB bank becomes 6 chunk launches
+    yield
+    ops.set_host_pipe(threads=4, slot_bytes=16 << 20, chunk_bytes=24 << 20)
+
+
+def _segments(rng, P, T, zeros=0):
+    cuts = np.sort(rng.integers(0, T + 1, size=P - 2))
+    seg = np.diff(np.concatenate([[0], cuts, [T]])).astype(np.int64)
+    for k in rng.choice(P - 1, size=zeros, replace=False):
+        if k + 1 < P - 1:
+            seg[k + 1] += seg[k]
+            seg[k] = 0
+    assert seg.sum() == T
+    return seg
+
+
+@pytest.mark.parametrize("T,P,C,L,zeros", [(120000, 40, 4, 10000, 0), (70001, 33, 3, 12345, 5), (50000, 64, 2, 9000, 0)])
+def test_chunked_host_render_same_bits_as_device_render(gpu, small_chunks, T, P, C, L, zeros):
+    from sonicsim_amd import ops
+    x, bank, _ = golden_inputs(90 + P, T, P, C, L)
+    seg = _segments(np.random.default_rng(P), P, T, zeros)
+    want = ops.convolve_moving_seg(torch.from_numpy(x).to(gpu), torch.from_numpy(bank).to(gpu), seg).cpu().numpy()
+    got = ops.convolve_moving_seg(x, bank, seg)
+    st = ops.host_path_stats()
+    assert isinstance(got, np.ndarray) and got.shape == (C, T)
+    assert st["chunks"] >= 2 and st["bytes_up"] == 4 * (T + P * C * L) and st["bytes_down"] == 4 * C * T, st
+    assert np.array_equal(got, want)
+    # twice in a row (ring slots and events are reused)
+    assert np.array_equal(ops.convolve_moving_seg(x, bank, seg), want)
+    # other slot sizes / thread counts: same bits
+    ops.set_host_pipe(threads=3, slot_bytes=1 << 18)
+    assert np.array_equal(ops.convolve_moving_seg(x, bank, seg), want)
+    ops.set_host_pipe(threads=1, slot_bytes=8 << 20)
+    assert np.array_equal(ops.convolve_moving_seg(x, bank, seg), want)
+
+
+def test_pinned_buffers_take_the_direct_path(gpu, small_chunks):
+    from sonicsim_amd import ops
+    T, P, C, L = 90000, 36, 4, 9500
+    x, bank, _ = golden_inputs(7, T, P, C, L)
+    seg = _segments(np.random.default_rng(3), P, T)
+    want = ops.convolve_moving_seg(torch.from_numpy(x).to(gpu), torch.from_numpy(bank).to(gpu), seg).cpu().numpy()
+    px, pb, py = ops.pinned_empty((T,)), ops.pinned_empty((P, C, L)), ops.pinned_empty((C, T))
+    px[:] = x
+    pb[:] = bank
+    py[:] = np.nan
+    got = ops.convolve_moving_seg(px, pb, seg, out=py)
+    st = ops.host_path_stats()
+    assert got is py and st["direct_transfers"] >= 3, st
+    assert np.array_equal(py, want)
+    # pageable inputs into a pinned output, and the reverse
+    py[:] = np.nan
+    assert np.array_equal(ops.convolve_moving_seg(x, bank, seg, out=py), want)
+    assert np.array_equal(ops.convolve_moving_seg(px, pb, seg), want)
+    with pytest.raises(ValueError):
+        ops.convolve_moving_seg(x, bank, seg, out=np.empty((C, T + 1), np.float32))
+
+
+def test_resident_bank_host_signal(gpu):
+    """SS_FLAG_BANK_DEVICE: only x and y cross PCIe"""
+    from sonicsim_amd import ops
+    T, P, C, L = 100000, 20, 4, 9000
+    x, bank, _ = golden_inputs(11, T, P, C, L)
+    seg = _segments(np.random.default_rng(5), P, T)
+    dbank = torch.from_numpy(bank).to(gpu)
+    want = ops.convolve_moving_seg(torch.from_numpy(x).to(gpu), dbank, seg).cpu().numpy()
+    got = ops.convolve_moving_seg(x, dbank, seg, host_io=True)
+    st = ops.host_path_stats()
+    assert isinstance(got, np.ndarray) and st["bytes_up"] == 4 * T and st["bytes_down"] == 4 * C * T, st
+    assert np.array_equal(got, want)
+
+
+def test_explicit_schedule_fixed_receiver_and_short_filters_through_the_ring(gpu, small_chunks):
+    from oracle import moving as O
+    from sonicsim_amd import ops
+    T, P, C, L = 60000, 12, 3, 9000
+    x, bank, _ = golden_inputs(21, T, P, C, L)
+    seg = _segments(np.random.default_rng(8), P, T)
+    idx, w = O.expand_segments(seg)
+    dx, db = torch.from_numpy(x).to(gpu), torch.from_numpy(bank).to(gpu)
+    want = ops.convolve_moving(dx, db, torch.from_numpy(idx).to(gpu), torch.from_numpy(w).to(gpu)).cpu().numpy()
+    assert np.array_equal(ops.convolve_moving(x, bank, idx, w), want)                      # one launch behind a pipelined upload
+    assert np.array_equal(ops.convolve_fixed(x, bank[0]), ops.convolve_fixed(dx, db[0]).cpu().numpy())
+    xs, bs, _ = golden_inputs(22, 5000, 6, 2, 100)                                          # direct-form engine, tiny transfers
+    segs = _segments(np.random.default_rng(9), 6, 5000)
+    assert np.array_equal(ops.convolve_moving_seg(xs, bs, segs),
+                          ops.convolve_moving_seg(torch.from_numpy(xs).to(gpu), torch.from_numpy(bs).to(gpu), segs).cpu().numpy())
+    with pytest.raises(ValueError):
+        ops.convolve_moving(x, bank, idx + P, w)                                            # out-of-range index still raises at the call
+
+
+def test_config2_host_path_full_size(gpu):
+    """the whole config-2 render from pageable NumPy arrays: same bits as the resident render, and the time it takes"""
+    import time
+    from sonicsim_amd import ops, synth
+    ops.init(0)
+    sc = synth.make_scene("cfg2", scene=0)
+    seg = synth.scene_segments(sc, 0)
+    dbank = ops.rir_bank_synth(sc.delay, sc.dgain, sc.L, sc.fs, sc.rt60, sc.bank_seed, device=gpu)
+    ops.peak_normalize_(dbank)
+    want = ops.convolve_moving_seg(torch.from_numpy(sc.x).to(gpu), dbank, seg).cpu().numpy()
+    bank = dbank.cpu().numpy()
+    got = ops.convolve_moving_seg(sc.x, bank, seg)
+    assert np.array_equal(got, want)
+    best = 1e9
+    for _ in range(3):
+        t0 = time.perf_counter()
+        got = ops.convolve_moving_seg(sc.x, bank, seg)
+        best = min(best, time.perf_counter() - t0)
+    st = ops.host_path_stats()
+    print(f"config 2 from pageable host arrays: {best * 1e3:.2f} ms per render ({(st['bytes_up'] + st['bytes_down']) / best / 1e9:.1f} GB/s "
+          f"over PCIe, {st['chunks']} chunks, {st['threads']} copy threads)")
+    assert np.array_equal(got, want) and st["chunks"] >= 8

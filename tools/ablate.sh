@@ -1,6 +1,6 @@
 #!/bin/bash
 # Run on the GPU box: time the HIP render engines under each profiling-only ablation mask (results are WRONG when != 0).
-# The ladder is compiled only with -DSS_ABLATE:  python -c "from sonicsim_amd import build; build.build(extra=['-DSS_ABLATE'], out='/tmp/libss_ablate.so')"  then SS_LIB=/tmp/libss_ablate.so
+# The ladder is compiled only with -DSS_ABLATE:  python -c "from sonicsim_amd import build; build.build(extra=['-DSS_ABLATE'], out='/tmp/libss_ablate.so')"  then BENCH_LIB=/tmp/libss_ablate.so
 # Usage: tools/ablate.sh "<masks>" [extra env]   -> one line per mask: mask, ms_per_step, k_os avg launch ms
 for m in $1; do
   SS_OS_ABLATE=$m python bench.py --steps 20 --warmup 3 --cpu-positions 0 2>/dev/null | python -c "

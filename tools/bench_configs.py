@@ -6,6 +6,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
 import torch
+import os as _os
+from sonicsim_amd import _lib as _sslib  # noqa: E402
+if _os.environ.get("BENCH_LIB"):
+    _sslib.use_library(_os.environ["BENCH_LIB"])     # A/B / tuning builds: explicit, never an environment switch of the product
 from sonicsim_amd import SonicSim_audio as A, ops, pipeline, synth, mixing
 
 dev = torch.device("cuda:0")

@@ -4,6 +4,10 @@ usage: python tools/check_asm.py [path ...]   (paths: asm os13 os4096)"""
 import sys, time
 import numpy as np, torch
 sys.path.insert(0, ".")
+import os as _os
+from sonicsim_amd import _lib as _sslib  # noqa: E402
+if _os.environ.get("BENCH_LIB"):
+    _sslib.use_library(_os.environ["BENCH_LIB"])     # A/B / tuning builds: explicit, never an environment switch of the product
 from sonicsim_amd import ops, synth
 from oracle import moving as O
 

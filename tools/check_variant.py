@@ -5,7 +5,9 @@ Prints one line: parity of the implicit / explicit / fixed schedules against the
 shapes, then the sustained kernel time at config 2 (HIP events around every launch, 200 launches after an 80 ms pre-roll)."""
 import os
 import sys
-os.environ.setdefault("SS_LIB", os.path.abspath("sonicsim_amd/lib/libsonicsim_hip_tuning.so"))   # experiment switches: tuning build
+sys.path.insert(0, ".")
+from sonicsim_amd import _lib as _sslib
+_sslib.use_library(os.environ.get("BENCH_LIB") or "sonicsim_amd/lib/libsonicsim_hip_tuning.so")   # experiment switches live in the tuning build
 import time
 
 import numpy as np

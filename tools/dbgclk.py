@@ -1,5 +1,9 @@
 import sys, ctypes, numpy as np, torch
 sys.path.insert(0, ".")
+import os as _os
+from sonicsim_amd import _lib as _sslib  # noqa: E402
+if _os.environ.get("BENCH_LIB"):
+    _sslib.use_library(_os.environ["BENCH_LIB"])     # A/B / tuning builds: explicit, never an environment switch of the product
 from sonicsim_amd import SonicSim_audio as A, ops, _lib
 ops.init(0)
 y = (0.05 * torch.randn(8, 960000, device="cuda:0")).contiguous()

@@ -1,7 +1,7 @@
 #!/bin/bash
 # tap loads non-temporal / sc1 vs default policy: kernel time (bench, interleaved) + FETCH_SIZE of the render kernel (one PMC pass each)
 OUT=gpurun_out/${1:-r03u}; mkdir -p $OUT
-export SS_LIB=sonicsim_amd/lib/libsonicsim_hip_tuning.so
+export BENCH_LIB=sonicsim_amd/lib/libsonicsim_hip_tuning.so
 for i in 1 2; do
   for v in base_dynq nttaps sc1taps; do
     SS_HSACO=$PWD/tools/var/$v.hsaco BENCH_NO_AB=1 python3 bench.py --steps 20 --warmup 5 --cpu-seconds 0 --windows 5 > $OUT/${v}_$i.json 2>$OUT/err.log

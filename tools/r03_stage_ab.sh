@@ -10,7 +10,7 @@ PY
 }
 for i in 1 2; do
   for m in 2 1; do
-    SS_LIB=sonicsim_amd/lib/libsonicsim_hip_tuning.so SS_ZERO_COPY_PLAN=$m python3 bench.py --steps 20 --warmup 5 --cpu-seconds 0 > $OUT/mode${m}_$i.json 2>$OUT/err.log; show $OUT/mode${m}_$i.json
+    BENCH_LIB=sonicsim_amd/lib/libsonicsim_hip_tuning.so SS_ZERO_COPY_PLAN=$m python3 bench.py --steps 20 --warmup 5 --cpu-seconds 0 > $OUT/mode${m}_$i.json 2>$OUT/err.log; show $OUT/mode${m}_$i.json
   done
 done
 python3 tools/t_outliers.py 4 dynq static > $OUT/outliers_mode2.log 2>>$OUT/err.log; cut -c1-400 $OUT/outliers_mode2.log

@@ -3,7 +3,7 @@
 OUT=gpurun_out/${1:-r03q}; mkdir -p $OUT
 for i in 1 2; do
   for t in 12 0 20 30 45; do
-    SS_PLAN_TAIL=$t SS_LIB=sonicsim_amd/lib/libsonicsim_hip_tuning.so BENCH_NO_AB=1 python3 bench.py --steps 20 --warmup 5 --cpu-seconds 0 --windows 5 > $OUT/tail${t}_$i.json 2>$OUT/err.log
+    SS_PLAN_TAIL=$t BENCH_LIB=sonicsim_amd/lib/libsonicsim_hip_tuning.so BENCH_NO_AB=1 python3 bench.py --steps 20 --warmup 5 --cpu-seconds 0 --windows 5 > $OUT/tail${t}_$i.json 2>$OUT/err.log
     python3 - $OUT/tail${t}_$i.json $t <<'PY'
 import json,sys
 j=json.load(open(sys.argv[1])); w=j["windows"]; r=j["roofline"]

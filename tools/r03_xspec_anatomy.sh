@@ -9,6 +9,6 @@ print(sys.argv[1].split("/")[-1], "ms/step %s | kernel %s | xspec %s" % (["%.4f"
 PY
 }
 for i in 1 2; do
-  SS_LIB=sonicsim_amd/lib/libsonicsim_hip_tuning.so BENCH_NO_AB=1 python3 bench.py --steps 20 --warmup 5 --cpu-seconds 0 > $OUT/zfill_$i.json 2>$OUT/err.log; show $OUT/zfill_$i.json
-  SS_NO_ZFILL=1 SS_LIB=sonicsim_amd/lib/libsonicsim_hip_tuning.so BENCH_NO_AB=1 python3 bench.py --steps 20 --warmup 5 --cpu-seconds 0 > $OUT/nozfill_$i.json 2>$OUT/err.log; show $OUT/nozfill_$i.json
+  BENCH_LIB=sonicsim_amd/lib/libsonicsim_hip_tuning.so BENCH_NO_AB=1 python3 bench.py --steps 20 --warmup 5 --cpu-seconds 0 > $OUT/zfill_$i.json 2>$OUT/err.log; show $OUT/zfill_$i.json
+  SS_NO_ZFILL=1 BENCH_LIB=sonicsim_amd/lib/libsonicsim_hip_tuning.so BENCH_NO_AB=1 python3 bench.py --steps 20 --warmup 5 --cpu-seconds 0 > $OUT/nozfill_$i.json 2>$OUT/err.log; show $OUT/nozfill_$i.json
 done

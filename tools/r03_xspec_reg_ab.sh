@@ -3,7 +3,7 @@
 OUT=gpurun_out/${1:-r03y}; mkdir -p $OUT
 for i in 1 2 3; do
   for v in before after; do
-    if [ $v = before ]; then export SS_LIB=$PWD/tools/var/libsonicsim_hip_before.so; else unset SS_LIB; fi
+    if [ $v = before ]; then export BENCH_LIB=$PWD/tools/var/libsonicsim_hip_before.so; else unset BENCH_LIB; fi
     BENCH_NO_AB=1 python3 bench.py --steps 20 --warmup 5 --cpu-seconds 0 --windows 5 > $OUT/${v}_$i.json 2>$OUT/err.log
     python3 - $OUT/${v}_$i.json $v <<'PY'
 import json,sys
@@ -12,5 +12,5 @@ print("%-7s value %.0f  ms/step median %.4f  kernel median %.4f  xspec (events) 
 PY
   done
 done
-unset SS_LIB
+unset BENCH_LIB
 

@@ -9,6 +9,6 @@ print(sys.argv[1].split("/")[-1], "value %.0f cold %.0f ms/step %s kernel all-wi
 PY
 }
 for i in 1 2; do
-  SS_LIB=sonicsim_amd/lib/libsonicsim_hip_tuning.so python3 bench.py --steps 20 --warmup 5 --cpu-seconds 0 > $OUT/zc1_$i.json 2>$OUT/err.log; show $OUT/zc1_$i.json
-  SS_LIB=sonicsim_amd/lib/libsonicsim_hip_tuning.so SS_ZERO_COPY_PLAN=0 python3 bench.py --steps 20 --warmup 5 --cpu-seconds 0 > $OUT/zc0_$i.json 2>$OUT/err.log; show $OUT/zc0_$i.json
+  BENCH_LIB=sonicsim_amd/lib/libsonicsim_hip_tuning.so python3 bench.py --steps 20 --warmup 5 --cpu-seconds 0 > $OUT/zc1_$i.json 2>$OUT/err.log; show $OUT/zc1_$i.json
+  BENCH_LIB=sonicsim_amd/lib/libsonicsim_hip_tuning.so SS_ZERO_COPY_PLAN=0 python3 bench.py --steps 20 --warmup 5 --cpu-seconds 0 > $OUT/zc0_$i.json 2>$OUT/err.log; show $OUT/zc0_$i.json
 done

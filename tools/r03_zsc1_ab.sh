@@ -9,6 +9,6 @@ print(sys.argv[1].split("/")[-1], "value %.0f ms/step %s | events: %s kernel med
 PY
 }
 for i in 1 2; do
-  SS_LIB=sonicsim_amd/lib/libsonicsim_hip_tuning.so BENCH_NO_AB=1 python3 bench.py --steps 20 --warmup 5 --cpu-seconds 0 > $OUT/plain_$i.json 2>$OUT/err.log; show $OUT/plain_$i.json
-  SS_LIB=sonicsim_amd/lib/libsonicsim_hip_zsc1.so BENCH_NO_AB=1 python3 bench.py --steps 20 --warmup 5 --cpu-seconds 0 > $OUT/zsc1_$i.json 2>$OUT/err.log; show $OUT/zsc1_$i.json
+  BENCH_LIB=sonicsim_amd/lib/libsonicsim_hip_tuning.so BENCH_NO_AB=1 python3 bench.py --steps 20 --warmup 5 --cpu-seconds 0 > $OUT/plain_$i.json 2>$OUT/err.log; show $OUT/plain_$i.json
+  BENCH_LIB=sonicsim_amd/lib/libsonicsim_hip_zsc1.so BENCH_NO_AB=1 python3 bench.py --steps 20 --warmup 5 --cpu-seconds 0 > $OUT/zsc1_$i.json 2>$OUT/err.log; show $OUT/zsc1_$i.json
 done

@@ -4,6 +4,10 @@ import sys, time
 sys.path.insert(0, ".")
 import numpy as np, torch
 from oracle import moving as O
+import os as _os
+from sonicsim_amd import _lib as _sslib  # noqa: E402
+if _os.environ.get("BENCH_LIB"):
+    _sslib.use_library(_os.environ["BENCH_LIB"])     # A/B / tuning builds: explicit, never an environment switch of the product
 from sonicsim_amd import ops, synth
 ops.init(0); dev = torch.device("cuda:0")
 for cfg in ("cfg2", "cfg5"):

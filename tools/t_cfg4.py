@@ -7,6 +7,10 @@ sys.path.insert(0, ".")
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
+import os as _os
+from sonicsim_amd import _lib as _sslib  # noqa: E402
+if _os.environ.get("BENCH_LIB"):
+    _sslib.use_library(_os.environ["BENCH_LIB"])     # A/B / tuning builds: explicit, never an environment switch of the product
 from sonicsim_amd import ops, parallel, pipeline  # noqa: E402
 
 dev = torch.device("cuda:0")

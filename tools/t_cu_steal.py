@@ -5,6 +5,10 @@ Prints both modes (ops.set_task_queue)."""
 import ctypes, os, sys, time
 sys.path.insert(0, ".")
 import numpy as np, torch
+import os as _os
+from sonicsim_amd import _lib as _sslib  # noqa: E402
+if _os.environ.get("BENCH_LIB"):
+    _sslib.use_library(_os.environ["BENCH_LIB"])     # A/B / tuning builds: explicit, never an environment switch of the product
 from sonicsim_amd import ops, synth
 ops.init(0)
 dev = torch.device("cuda:0")

@@ -1,6 +1,10 @@
 """GPU box: host-side enqueue time of one config-2 render call versus its GPU time (is the step host-bound?)."""
 import sys, time, numpy as np, torch
 sys.path.insert(0, ".")
+import os as _os
+from sonicsim_amd import _lib as _sslib  # noqa: E402
+if _os.environ.get("BENCH_LIB"):
+    _sslib.use_library(_os.environ["BENCH_LIB"])     # A/B / tuning builds: explicit, never an environment switch of the product
 from sonicsim_amd import ops, synth
 ops.init(0)
 dev = torch.device("cuda:0")

@@ -1,5 +1,7 @@
 import sys, time, os
-os.environ.setdefault("SS_LIB", os.path.abspath("sonicsim_amd/lib/libsonicsim_hip_tuning.so"))   # SS_SYNTH_V lives in the tuning build
+sys.path.insert(0, ".")
+from sonicsim_amd import _lib as _sslib
+_sslib.use_library(os.environ.get("BENCH_LIB") or "sonicsim_amd/lib/libsonicsim_hip_tuning.so")   # experiment switches live in the tuning build
 sys.path.insert(0, ".")
 import torch, numpy as np
 from sonicsim_amd import ops, synth

@@ -3,7 +3,7 @@
 inside a 20-step window is exactly round 2's driver-timed 0.258 ms/step)?  Runs back-to-back config-2 renders for `secs` per mode and
 counts launches > 1.5 x median, with their time stamps (periodic?).
    modes: dynq | static | dynq_tel (sysfs sampler thread on) | divide (a plain HIP streaming kernel instead of the render)
-   python tools/t_outliers.py <secs> <mode> [<mode> ...]      (SS_LIB=...tuning.so SS_ZERO_COPY_PLAN=0 for the plan-in-HBM variant)"""
+   python tools/t_outliers.py <secs> <mode> [<mode> ...]      (BENCH_LIB=...tuning.so SS_ZERO_COPY_PLAN=0 for the plan-in-HBM variant)"""
 import json
 import os
 import sys
@@ -14,6 +14,10 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 import bench  # noqa: E402
+import os as _os
+from sonicsim_amd import _lib as _sslib  # noqa: E402
+if _os.environ.get("BENCH_LIB"):
+    _sslib.use_library(_os.environ["BENCH_LIB"])     # A/B / tuning builds: explicit, never an environment switch of the product
 from sonicsim_amd import ops, synth  # noqa: E402
 
 secs = float(sys.argv[1])

@@ -1,7 +1,9 @@
 """GPU box: per-workgroup (start, end) wall-clock stamps of one k_os13_asm launch (code object built with OS13_OPT=wgclk).
 usage: SS_HSACO=$PWD/tools/var/wgclk.hsaco SS_TRACE_FILE=gpurun_out/wgclk.bin [SS_DYNQ=0] python tools/wgclk.py"""
 import os, sys, numpy as np, torch
-os.environ.setdefault("SS_LIB", os.path.abspath("sonicsim_amd/lib/libsonicsim_hip_tuning.so"))   # experiment switches: tuning build
+sys.path.insert(0, ".")
+from sonicsim_amd import _lib as _sslib
+_sslib.use_library(os.environ.get("BENCH_LIB") or "sonicsim_amd/lib/libsonicsim_hip_tuning.so")   # experiment switches live in the tuning build
 sys.path.insert(0, ".")
 from sonicsim_amd import ops, synth
 ops.init(0)
