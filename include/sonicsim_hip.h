@@ -99,10 +99,12 @@ int ss_set_task_queue(int dynamic);
  * that no later chunk touches travels back at once.  Same bits as the device-pointer render.  Buffers the caller pinned itself
  * (ss_host_alloc, hipHostMalloc, hipHostRegister) are recognised and moved by DMA directly, without the staging copy.
  * ss_set_host_pipe: copy threads (0 = keep; default 4: more only contend for the memory system, profiles/r04a), bytes per staging slot (default 16 MiB, 6 up + 4 down),
- * bytes per bank chunk (default 24 MiB, at most 16 chunks) -- current device.
+ * bytes per bank chunk (default 24 MiB, at most 16 chunks), bind (-1 = keep, 0 = default: the copy threads are left to the scheduler, 1 = bound to
+ * the CPUs next to the GPU -- sysfs local_cpulist of its PCI function; measured SLOWER when the caller's arrays live on the other socket,
+ * profiles/r04d) -- current device.
  * ss_host_path_stats: {seconds inside the last host-pointer render call, bytes up, bytes down, bank chunks, direct (pinned) transfers,
  * copy threads} of the current device. */
-int ss_set_host_pipe(int threads, int64_t slot_bytes, int64_t chunk_bytes);
+int ss_set_host_pipe(int threads, int64_t slot_bytes, int64_t chunk_bytes, int bind);
 int ss_host_path_stats(double* out, int32_t n);
 /* pinned host memory the DMA engines address directly (hipHostMalloc / hipHostFree): a caller that renders into such a buffer skips the
  * staging copy of host-pointer mode */

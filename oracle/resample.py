@@ -64,3 +64,41 @@ def resample(waveform, orig_freq, new_freq, lowpass_filter_width=6, rolloff=0.99
     y = y.reshape(x2.shape[0], -1)
     target = int(math.ceil(new * L / orig))
     return y[:, :target].reshape(shape[:-1] + (target,))
+
+
+def resample_exact_f64(waveform, orig_freq, new_freq, lowpass_filter_width=6, rolloff=0.99):
+    """A SECOND, independent statement of the same filter (round 4): band-limited interpolation evaluated from its definition at the exact
+    rational output times, in float64 -- no phases, no frames, no padding, no gcd reduction, no kernel table:
+
+        y[m] = sum_n x[n] * h(n / orig_freq - m / new_freq),     h(s) = (B / orig_freq) * sinc(B s) * cos^2(pi B s / (2 w)) for |B s| < w, else 0
+
+    with B = min(orig_freq, new_freq) * rolloff (the cut-off in Hz) and w = lowpass_filter_width (zero crossings kept on each side).
+    Time differences are formed from the INTEGER n * new_freq - m * orig_freq, so there is no accumulated time error.  What it pins is the
+    indexing of the polyphase form above (frame / phase split, the (width, width + orig) padding, the crop, the trimming of zero taps in
+    the product's tap table); what it cannot pin is torchaudio's choice of B, w and the window, which both statements take from the
+    published algorithm.  The polyphase form with float32 taps and float32 accumulation agrees with it to float32 round-off (bound in
+    tests/test_assembly.py: 4e-6 of the input's peak)."""
+    x = np.asarray(waveform, dtype=np.float64)
+    of, nf = int(orig_freq), int(new_freq)
+    if of == nf:
+        return x.copy()
+    shape = x.shape
+    x2 = x.reshape(-1, shape[-1])
+    L = shape[-1]
+    Lout = -(-nf * L // of)                                            # ceil(new * L / orig)
+    B = min(of, nf) * rolloff
+    w = float(lowpass_filter_width)
+    half = int(math.ceil(w * of / B)) + 1                              # input samples on each side of the output instant
+    m = np.arange(Lout, dtype=np.int64)
+    centre = (m * of) // nf                                            # floor of the output instant in input samples
+    offs = np.arange(-half, half + 2, dtype=np.int64)
+    n = centre[:, None] + offs[None, :]                                # (Lout, K) candidate input samples
+    num = n * nf - (m * of)[:, None]                                   # exact: (n / of - m / nf) * of * nf
+    t = B * num.astype(np.float64) / (float(of) * float(nf))           # B s
+    inside = (np.abs(t) < w) & (n >= 0) & (n < L)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        h = np.where(t == 0, 1.0, np.sin(math.pi * t) / (math.pi * t)) * np.cos(math.pi * t / (2.0 * w)) ** 2 * (B / of)
+    h = np.where(inside, h, 0.0)
+    nn = np.clip(n, 0, L - 1)
+    y = np.einsum("rmk,mk->rm", x2[:, nn], h)
+    return y.reshape(shape[:-1] + (Lout,))

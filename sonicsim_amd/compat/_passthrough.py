@@ -2,7 +2,8 @@
 (``SonicSim-SonicSet/``), import it under a private name and hand back its public names, so that everything the MI355X package
 does not accelerate (``Scene``, ``get_nav_idx``, ``save_trace_gif``, ...: Habitat-side code, out of scope) still resolves when
 ``sonicsim_amd/compat`` shadows the reference's modules.  If the reference is not on the path -- or cannot be imported because
-Habitat / magnum / torchaudio are missing -- only the accelerated names exist, exactly as before."""
+Habitat / magnum / torchaudio are missing (ImportError) -- only the accelerated names exist, exactly as before; any other exception
+raised while the reference module executes is a bug in that file and is re-raised."""
 import importlib.util
 import os
 import sys
@@ -25,8 +26,11 @@ def reference_names(module_name):
                 sys.modules[alias] = mod
                 try:
                     spec.loader.exec_module(mod)
-                except Exception as e:                      # missing Habitat etc.: the accelerated subset still works
-                    del sys.modules[alias]
-                    return {}, f"{cand}: {type(e).__name__}: {e}"
+                except ImportError as e:                    # (incl. ModuleNotFoundError) missing Habitat / magnum / torchaudio: the
+                    del sys.modules[alias]                  # accelerated subset still works.  Anything ELSE -- a genuine bug in a user's
+                    return {}, f"{cand}: {type(e).__name__}: {e}"     # modified reference file -- propagates instead of degrading silently
+                except BaseException:
+                    sys.modules.pop(alias, None)
+                    raise
             return {k: v for k, v in vars(mod).items() if not k.startswith("_")}, cand
     return {}, None

@@ -4,6 +4,10 @@
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
 
+#include <pthread.h>
+#include <sched.h>
+
+#include <cctype>
 #include <chrono>
 #include <condition_variable>
 #include <deque>
@@ -1731,8 +1735,10 @@ int render(int mode, const float* x, int64_t T, const float* bank, int32_t P, in
     const size_t bank_bytes = sizeof(float) * (size_t)P * C * L;
     HostPipe& hp = c->pipe;
     const auto host_t0 = std::chrono::steady_clock::now();
+    auto mark = [&](int i) { if (!dev) hp.st_mark[i] = std::chrono::duration<double>(std::chrono::steady_clock::now() - host_t0).count(); };
     if (!dev) {
         if ((rc = hp_ensure(hp))) return rc;
+        for (double& m : hp.st_mark) m = 0;
         hp.pending.clear();
         hp.evused = 0;
         hp.st_bytes_up = hp.st_bytes_down = hp.st_seconds = 0;
@@ -1744,6 +1750,7 @@ int render(int mode, const float* x, int64_t T, const float* bank, int32_t P, in
             if ((rc = ws_ensure(c, WS_IDX, sizeof(int64_t) * T))) return rc;
             if ((rc = ws_ensure(c, WS_W, sizeof(float) * T))) return rc;
         }
+        mark(0);
         if ((rc = hp_upload(hp, c->ws[WS_X], x, sizeof(float) * T))) return rc;
         dx = (const float*)c->ws[WS_X];
         if (!bank_dev) dbank = (const float*)c->ws[WS_BANK];
@@ -1758,6 +1765,7 @@ int render(int mode, const float* x, int64_t T, const float* bank, int32_t P, in
         if ((rc = hp_event(hp, &e_in))) return rc;
         HIPCHK(hipEventRecord(e_in, hp.up));
         HIPCHK(hipStreamWaitEvent(stream, e_in, 0));
+        mark(1);
     }
 
     // ---- engine choice
@@ -1948,6 +1956,7 @@ int render(int mode, const float* x, int64_t T, const float* bank, int32_t P, in
         plan_base = (const char*)c->ws[WS_PLAN];
     }
 
+    mark(2);
     int qgroups = 0, qinit = 0;
     const char* trace_env = knob("SS_TRACE_FILE");      // timeline trace of a code object built with OS13_OPT=trace (tools/)
     RenderParams prm;
@@ -1989,6 +1998,7 @@ int render(int mode, const float* x, int64_t T, const float* bank, int32_t P, in
         HIPCHK(hipGetLastError());
     }
     const Task* dtasks = (const Task*)(plan_base + seg_bytes);
+    mark(3);
     if (chunked) {
         const size_t pos_bytes = sizeof(float) * (size_t)C * L;      // one trajectory position of the bank
         int64_t done = 0;
@@ -2037,7 +2047,9 @@ int render(int mode, const float* x, int64_t T, const float* bank, int32_t P, in
             return SS_OK;
         };
         if ((rc = hp_upload(hp, c->ws[WS_BANK], bank, bank_bytes, launch_ready))) return rc;
+        mark(4); mark(5);
         if ((rc = hp_finish(hp))) return rc;
+        mark(6);
         HIPCHK(hipStreamSynchronize(stream));
         hp.st_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - host_t0).count();
         return SS_OK;
@@ -2128,8 +2140,11 @@ int render(int mode, const float* x, int64_t T, const float* bank, int32_t P, in
         if ((rc = hp_event(hp, &e_done))) return rc;
         HIPCHK(hipEventRecord(e_done, stream));
         HIPCHK(hipStreamWaitEvent(hp.down, e_done, 0));
+        mark(4);
         if ((rc = hp_download(hp, y, 0, dy, 0, sizeof(float) * (size_t)C * T, 1))) return rc;
+        mark(5);
         if ((rc = hp_finish(hp))) return rc;
+        mark(6);
         HIPCHK(hipStreamSynchronize(stream));
         hp.st_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - host_t0).count();
     }
@@ -2319,7 +2334,7 @@ int ss_convolve_moving_f32(const float* x, int64_t T, const float* rirs, int32_t
     return render(COEF_EXPLICIT, x, T, rirs, P, C, L, nullptr, idx, w, y, flags, stream);
 }
 
-int ss_set_host_pipe(int threads, int64_t slot_bytes, int64_t chunk_bytes) {
+int ss_set_host_pipe(int threads, int64_t slot_bytes, int64_t chunk_bytes, int bind) {
     Ctx* c;
     int rc = get_ctx(&c);
     if (rc) return rc;
@@ -2327,13 +2342,15 @@ int ss_set_host_pipe(int threads, int64_t slot_bytes, int64_t chunk_bytes) {
     HostPipe& h = c->pipe;
     if (threads > 256 || (slot_bytes > 0 && (slot_bytes < (1 << 16) || slot_bytes > ((int64_t)1 << 30))) || (chunk_bytes > 0 && chunk_bytes < (1 << 20)))
         return fail(SS_EINVAL, "ss_set_host_pipe: threads <= 256, 64 KiB <= slot_bytes <= 1 GiB, chunk_bytes >= 1 MiB (0 / negative = keep)");
-    if (slot_bytes > 0 && (size_t)slot_bytes != h.slot_bytes) {
+    const bool rebind = bind >= 0 && (bind != 0) != h.bind;
+    if (rebind) h.bind = bind != 0;
+    if ((slot_bytes > 0 && (size_t)slot_bytes != h.slot_bytes) || rebind) {
         if (h.up) {
             HIPCHK(hipStreamSynchronize(h.up));
             HIPCHK(hipStreamSynchronize(h.down));
         }
         hp_destroy(h);
-        h.slot_bytes = (size_t)slot_bytes;
+        if (slot_bytes > 0) h.slot_bytes = (size_t)slot_bytes;
     }
     if (chunk_bytes > 0) h.chunk_bytes = (size_t)chunk_bytes;
     if (threads > 0) {
@@ -2350,8 +2367,9 @@ int ss_host_path_stats(double* out, int32_t n) {
     if (rc) return rc;
     std::lock_guard<std::mutex> lock(c->mu);
     const HostPipe& h = c->pipe;
-    const double v[6] = {h.st_seconds, h.st_bytes_up, h.st_bytes_down, (double)h.st_chunks, (double)h.st_direct, (double)h.threads};
-    for (int i = 0; i < n && i < 6; ++i) out[i] = v[i];
+    double v[14] = {h.st_seconds, h.st_bytes_up, h.st_bytes_down, (double)h.st_chunks, (double)h.st_direct, (double)h.threads};
+    for (int i = 0; i < 8; ++i) v[6 + i] = h.st_mark[i];
+    for (int i = 0; i < n && i < 14; ++i) out[i] = v[i];
     return SS_OK;
 }
 

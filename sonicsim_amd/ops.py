@@ -125,16 +125,18 @@ def pinned_empty(shape, dtype=np.float32):
     return np.frombuffer(raw, dtype=dt, count=int(np.prod(shape))).reshape(shape)
 
 
-def set_host_pipe(threads=0, slot_bytes=0, chunk_bytes=0):
-    """Host-pointer mode tuning on the current device (0 = keep): copy threads, bytes per pinned staging slot, bytes per bank chunk."""
-    _lib.check(_lib.load().ss_set_host_pipe(int(threads), int(slot_bytes), int(chunk_bytes)))
+def set_host_pipe(threads=0, slot_bytes=0, chunk_bytes=0, bind=None):
+    """Host-pointer mode tuning on the current device (0 / None = keep): copy threads, bytes per pinned staging slot, bytes per bank chunk,
+    bind = whether the copy threads are bound to the CPUs next to the GPU (default False: measured slower)."""
+    _lib.check(_lib.load().ss_set_host_pipe(int(threads), int(slot_bytes), int(chunk_bytes), -1 if bind is None else int(bool(bind))))
 
 
 def host_path_stats():
     """{seconds, bytes_up, bytes_down, chunks, direct_transfers, threads} of the last host-pointer render on the current device."""
-    v = (ctypes.c_double * 6)()
-    _lib.check(_lib.load().ss_host_path_stats(v, 6))
-    return {"seconds": v[0], "bytes_up": v[1], "bytes_down": v[2], "chunks": int(v[3]), "direct_transfers": int(v[4]), "threads": int(v[5])}
+    v = (ctypes.c_double * 14)()
+    _lib.check(_lib.load().ss_host_path_stats(v, 14))
+    return {"seconds": v[0], "bytes_up": v[1], "bytes_down": v[2], "chunks": int(v[3]), "direct_transfers": int(v[4]), "threads": int(v[5]),
+            "marks_ms": [round(v[6 + i] * 1e3, 4) for i in range(7)]}
 
 
 def _out_ct(out, C, T, dev):

@@ -106,6 +106,40 @@ def test_assembly_with_gpu_resampler(gpu, tmp_path, monkeypatch):
             assert np.abs(long_audio.numpy() - ref).max() < 2e-6 * np.abs(ref).max()
 
 
+RESAMPLE_CASES = ((44100, 16000, 44100 * 2 + 17, 2), (48000, 16000, 30001, 1), (16000, 44100, 9000, 3), (22050, 16000, 12345, 1), (8000, 16000, 777, 1))
+EXACT_BOUND = 4e-7          # of the input's peak: float32 taps + float32 accumulation against the float64 definition (measured 0.5-1.2e-7)
+
+
+def test_resample_oracle_against_the_exact_time_definition():
+    """row N3's arithmetic has no reference pin (torchaudio is absent); round 4 adds a SECOND, independent statement of the filter --
+    band-limited interpolation evaluated in float64 at the exact rational output instants, no phases / frames / padding / table -- and
+    the polyphase oracle must agree with it to float32 round-off.  (The pass-band error of 2e-4 quoted for the 440 Hz anchor is the
+    filter's own roll-off, not an implementation error: both statements show it.)"""
+    from oracle import resample as OR
+    rng = np.random.default_rng(3)
+    for (o, n, L, rows) in RESAMPLE_CASES:
+        x = rng.standard_normal((rows, L)).astype(np.float32)
+        a, b = OR.resample(x, o, n), OR.resample_exact_f64(x, o, n)
+        assert a.shape == b.shape and np.abs(a - b).max() <= EXACT_BOUND * np.abs(x).max(), (o, n, np.abs(a - b).max())
+    fs = 44100
+    t = np.arange(fs) / fs
+    s440 = np.sin(2 * np.pi * 440 * t)
+    e = OR.resample_exact_f64(s440, fs, 16000)[100:-100] - np.sin(2 * np.pi * 440 * np.arange(16000) / 16000)[100:-100]
+    assert 1e-5 < np.abs(e).max() < 1e-3            # the definition itself deviates from the ideal resampler by the filter's ripple
+
+
+@pytest.mark.gpu
+def test_device_resampler_against_the_exact_time_definition(gpu):
+    from oracle import resample as OR
+    from sonicsim_amd.resample import resample
+    rng = np.random.default_rng(3)
+    for (o, n, L, rows) in RESAMPLE_CASES:
+        x = rng.standard_normal((rows, L)).astype(np.float32)
+        got = resample(torch.from_numpy(x).to(gpu), o, n).cpu().numpy()
+        want = OR.resample_exact_f64(x, o, n)
+        assert got.shape == want.shape and np.abs(got - want).max() <= EXACT_BOUND * np.abs(x).max(), (o, n, np.abs(got - want).max())
+
+
 @pytest.mark.gpu
 def test_resampler_against_oracle_and_anchors(gpu):
     from oracle import resample as OR

@@ -32,6 +32,26 @@ def test_compat_modules_pass_reference_names_through(tmp_path):
     assert r.returncode == 0 and "ok" in r.stdout, r.stderr
 
 
+def test_a_bug_in_the_users_reference_module_is_not_swallowed(tmp_path):
+    """only ImportError (a missing third-party package) degrades to "accelerated names only"; a genuine error in a user's modified
+    reference file propagates (round-3 verdict: `except Exception` hid it)"""
+    ref = tmp_path / "SonicSim-SonicSet"
+    ref.mkdir()
+    (ref / "SonicSim_audio.py").write_text("TABLE = {}\nVALUE = TABLE['typo']\n")
+    code = textwrap.dedent(f"""
+        import sys
+        sys.path[:0] = [{str(os.path.join(ROOT, 'sonicsim_amd', 'compat'))!r}, {str(ref)!r}]
+        try:
+            import SonicSim_audio
+        except KeyError as e:
+            print('raised KeyError', e)
+        else:
+            print('swallowed')
+    """)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "raised KeyError" in r.stdout, (r.stdout, r.stderr)
+
+
 SEQUENCE = '''
 import sys, gc
 sys.path.insert(0, COMPAT)

@@ -423,10 +423,10 @@ def test_mix_keep_speakers_and_vector_path(gpu):
 
 def test_device_loudness_ebu_tech_3341_cases(gpu):
     """the device path of row U (float64 K-weighting scan, block powers, gating on the GPU) on the published EBU Tech 3341 integrated-
-    loudness cases 1-5: within +-0.1 LU of the expected reading and within 1e-5 dB of the NumPy oracle"""
+    loudness cases 1-6: within +-0.1 LU of the expected reading and within 1e-5 dB of the NumPy oracle"""
     from sonicsim_amd import SonicSim_audio as A
     from util import ebu3341_case
-    for case in (1, 2, 3, 4, 5):
+    for case in (1, 2, 3, 4, 5, 6):                      # 6: 5.0-channel mode, surround weights 1.41
         x, want = ebu3341_case(case)
         got = A.integrated_loudness(torch.from_numpy(x).to(gpu), 48000)
         assert abs(got - want) <= 0.1, (case, got)

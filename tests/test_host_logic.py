@@ -137,13 +137,19 @@ def test_loudness_oracle_calibration():
 
 def test_loudness_oracle_ebu_tech_3341_cases():
     """Known-answer tests of the BS.1770-4 restatement that do not depend on pyloudnorm (absent here): the integrated-
-    loudness cases 1-5 of EBU Tech 3341, whose expected readings are published (+-0.1 LU) -- calibration, relative gate, absolute gate."""
+    loudness cases 1-6 of EBU Tech 3341, whose expected readings are published (+-0.1 LU) -- calibration, relative gate, absolute gate,
+    and the 5-channel case (channel weights)."""
     from oracle import loudness as O
     from util import ebu3341_case
-    for case in (1, 2, 3, 4, 5):
+    for case in (1, 2, 3, 4, 5, 6):                      # 6: the 5-channel case -- the surround weights 1.41 (round 4)
         x, want = ebu3341_case(case)
         got = O.integrated_loudness(x, 48000)
         assert abs(got - want) <= 0.1, (case, got)
+    x6, _ = ebu3341_case(6)
+    unit = O.gate.__globals__["G_WEIGHTS"]
+    assert tuple(unit) == (1.0, 1.0, 1.0, 1.41, 1.41)
+    # the weights matter: with the surrounds swapped into the front positions the reading moves by more than the tolerance
+    assert abs(O.integrated_loudness(x6[:, [3, 4, 2, 0, 1]], 48000) + 23.0) > 0.1
 
 
 def test_synth_scene_shapes():

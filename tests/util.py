@@ -94,7 +94,16 @@ def ebu3341_case(case, fs=48000):
       1: -23 dBFS, 20 s            -> -23.0      2: -33 dBFS, 20 s            -> -33.0
       3: -36 (10 s), -23 (60 s), -36 (10 s)                                   -> -23.0   (relative gate removes the quiet parts)
       4: -72 (10 s), -36 (10 s), -23 (60 s), -36 (10 s), -72 (10 s)           -> -23.0   (absolute gate as well)
-      5: -26 (20 s), -20 (20.1 s), -26 (20 s)                                 -> -23.0"""
+      5: -26 (20 s), -20 (20.1 s), -26 (20 s)                                 -> -23.0
+      6: 5.0-channel mode, 20 s: L = R = -28, C = -24, Ls = Rs = -30 dBFS         -> -23.0   (the only published check of the channel
+         weights: the surrounds count 1.41-fold, BS.1770-4 table 3; channel order L R C Ls Rs as in pyloudnorm's G = [1, 1, 1, 1.41, 1.41]).
+         Returns (T, 5)."""
+    if case == 6:
+        n = int(round(20.0 * fs))
+        t = np.arange(n) / fs
+        s = np.sin(2 * np.pi * 1000.0 * t)
+        lv = (-28.0, -28.0, -24.0, -30.0, -30.0)
+        return np.stack([(10.0 ** (v / 20.0) * s).astype(np.float32) for v in lv], axis=1), -23.0
     seqs = {1: [(-23, 20.0)], 2: [(-33, 20.0)], 3: [(-36, 10.0), (-23, 60.0), (-36, 10.0)],
             4: [(-72, 10.0), (-36, 10.0), (-23, 60.0), (-36, 10.0), (-72, 10.0)], 5: [(-26, 20.0), (-20, 20.1), (-26, 20.0)]}
     want = {1: -23.0, 2: -33.0, 3: -23.0, 4: -23.0, 5: -23.0}
