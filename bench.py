@@ -512,23 +512,39 @@ def run_scenes(args, rank, local_rank, world, dev):
     from sonicsim_amd import parallel, pipeline
 
     per_rank = args.steps
-    total = per_rank * world
-    pool = [pipeline.make_scene_spec(dev, scene=rank * 4 + i, config="cfg2") for i in range(min(4, per_rank))]   # dry signals + geometry cycle
+    total = int(args.scenes) if getattr(args, "scenes", None) else per_rank * world      # --scenes N: a total that need not divide (ragged last shard)
+    per_rank = -(-total // world)
+    scene_cfg = getattr(args, "scene_config", None) or "cfg2"
+    npool = min(4, per_rank)
+
+    def make_pool(r):
+        return [pipeline.make_scene_spec(dev, scene=r * 4 + i, config=scene_cfg) for i in range(npool)]   # dry signals + geometry cycle
+    pool = make_pool(rank)
     rend = pipeline.SceneRenderer(pool[0], dev, one_launch=os.environ.get("BENCH_SCENE_SEPARATE") != "1")
     gather = args.config == "cfg4" and not args.no_gather
-    np.random.seed(7000 + rank)
-    torch.manual_seed(7000 + rank)
     import gc
     gc.collect()
     gc.freeze()          # one generation-2 collection (40-60 ms with torch imported) would otherwise land inside the timed scenes (profiles/r02p)
 
-    def run(k, sg, base):
+    def draws(s):
+        """the host-side randomness of global scene s (SIR / SNR from torch.manual_seed(5000 + scene)); the loudness targets come
+        from the global NumPy stream, seeded per scene so that any rank can reproduce any scene"""
+        g = torch.Generator().manual_seed(5000 + int(s))
+        sir = torch.empty(1).uniform_(-6, 6, generator=g).numpy()
+        snr = float(torch.empty(1).uniform_(10, 20, generator=g).numpy()[0])
+        np.random.seed((9000 + int(s)) & 0x7FFFFFFF)
+        return sir, snr
+
+    def run(k, sg, base, pl=None):
         gains = []
+        pl = pl or pool
         for j in range(k):
-            spec = pool[j % len(pool)]
+            if sg is not None and sg.on and sg.scene(j) is None:        # ragged shard: this rank has no scene at step j, it only keeps the
+                sg.submit(j)                                            # gather's bookkeeping in step
+                continue
+            spec = pl[j % len(pl)]
             out = sg.slot(j) if sg is not None else None
-            sir = torch.Tensor(1).uniform_(-6, 6).numpy()
-            snr = float(torch.Tensor(1).uniform_(10, 20).numpy()[0])
+            sir, snr = draws(base + j)
             gains.append(rend.render(spec, seed=base + j, sirs=sir, snr=snr, out=out)[1])      # (5,) float64 on the device: no wait per scene
             if sg is not None:
                 sg.submit(j)
@@ -536,7 +552,7 @@ def run_scenes(args, rank, local_rank, world, dev):
         return sg.finish() if sg is not None else None
 
     lo = parallel.shard_range(total, rank, world)[0] if total else 0
-    run(max(1, args.warmup), parallel.SceneGather(max(1, args.warmup) * world, (pool[0].C, pool[0].T), device=dev) if gather else None, 10_000)
+    run(max(1, args.warmup), parallel.SceneGather(max(1, args.warmup) * world, (pool[0].C, pool[0].T), device=dev) if gather else None, 10_000_000)
     torch.cuda.synchronize()
     sg = parallel.SceneGather(total, (pool[0].C, pool[0].T), device=dev) if gather else None
     if world > 1:
@@ -548,6 +564,26 @@ def run_scenes(args, rank, local_rank, world, dev):
     if world > 1:
         dist.barrier()
     dt = parallel.barrier_max_seconds(time.perf_counter() - t0, device=dev)
+    # ---- the gathered scenes are the scenes: rank 0 re-renders a handful of them itself (first / last scene of a few ranks, the ragged last
+    #      shard included) from their global index alone and compares bits with what arrived
+    verify = None
+    if rank == 0 and res is not None and world > 1:
+        checked, bad = [], []
+        ranges = [parallel.shard_range(total, r, world) for r in range(world)]
+        for r in sorted(set([0, 1, world // 2, world - 1])):
+            if len(ranges[r]) == 0:
+                continue
+            plr = pool if r == 0 else make_pool(r)
+            for s in sorted(set([ranges[r][0], ranges[r][-1]])):
+                j = s - ranges[r][0]
+                sir, snr = draws(s)
+                mix, _ = rend.render(plr[j % len(plr)], seed=s, sirs=sir, snr=snr)
+                checked.append(int(s))
+                if not torch.equal(mix, res[s]):
+                    bad.append(int(s))
+            del plr
+        verify = {"scenes_rerendered_by_rank0": checked, "mismatching": bad, "same_bits": not bad,
+                  "shard_sizes": [len(x) for x in ranges]}
     if rank != 0:
         return None
     audio_s = pool[0].T / pool[0].fs
@@ -608,7 +644,7 @@ def run_scenes(args, rank, local_rank, world, dev):
                    "scene": "K1 x 5 (3 banks of 200 positions + 2 static IRs, produced inside the timed region, peak normalisation deferred into "
                             "the render), ONE ss_convolve_scene_f32 launch for the 3 moving + 2 static renders, ss_lufs_norm_batch_f32 (results stay on "
                             "the device; all gains are fetched once, inside the timed region), ss_mix_f32",
-                   "T": spec.T, "P": 200, "C": spec.C, "L": spec.L, "fs": spec.fs, "scenes_total": total,
+                   "T": spec.T, "P": len(pool[0].speakers[0][3]) + 1, "C": spec.C, "L": spec.L, "fs": spec.fs, "scenes_total": total,
                    "dry_signal_pool": len(pool), "gather": gather, "distributed": args.dist_info,
                    "gathered_bytes_at_root": int(total * spec.C * spec.T * 4) if gather else 0,
                    "renders_per_second": total * 5 / dt, "rendered_audio_sec_per_sec": total * 5 * audio_s / dt},
@@ -616,6 +652,7 @@ def run_scenes(args, rank, local_rank, world, dev):
         "lufs_gain_mean": float(run.gains.mean()) if getattr(run, "gains", None) is not None else None,
         "roofline": roof,
         "cpu_baseline": cpu,
+        "gather_verification": verify,
     }
 
 
@@ -885,6 +922,8 @@ def main():
     ap.add_argument("--windows", type=int, default=7, help="timed K-step windows of the sustained section (value = the median window)")
     ap.add_argument("--event-windows", type=int, default=None)
     ap.add_argument("--no-secondary", action="store_true", help="default run (cfg2, N = 1) without the legs for cfg5 / cfg4 / cfg1 / the host-pointer path")
+    ap.add_argument("--scenes", type=int, default=None, help="cfg3 / cfg4: total number of scenes over all ranks (default steps x ranks); need not divide")
+    ap.add_argument("--scene-config", default=None, help="cfg3 / cfg4: shapes of a scene's sources (default cfg2; 'tiny' for dry runs)")
     ap.add_argument("--legs", default=None, help="secondary legs of the default run, comma separated, in this order: host,cfg5,cfg4,cfg1 (default: all)")
     ap.add_argument("--lib", default=os.environ.get("BENCH_LIB"), help="measurement tools: another build of the library (tuning / A-B variants)")
     args = ap.parse_args()

@@ -96,6 +96,7 @@ class SceneGather:
         self.mine = self.ranges[self.rank]
         dtype = dtype or torch.float32
         self.cuda = device is not None and torch.device(device).type == "cuda"
+        self.host_backend = self.on and dist.get_backend() != "nccl"
         if self.rank == dst:
             self.result = torch.empty((num_scenes,) + tuple(shape), dtype=dtype, device=device)
             self.send = None
@@ -137,6 +138,11 @@ class SceneGather:
             ops.append(dist.P2POp(dist.isend, self.send[j % self.depth], self.dst))
         if not ops:
             return
+        if self.cuda and self.host_backend:
+            # the gloo harness (several ranks time-sharing one GPU, no RCCL): gloo's point-to-point calls take the tensor's address as a
+            # HOST pointer and read / write device memory through the PCIe BAR with no regard for streams (round 4, profiles/r04e: three of
+            # eight spot-checked scenes arrived stale).  The render must have finished before the send starts.
+            torch.cuda.current_stream().synchronize()
         if self.cuda:
             self.side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.side):
