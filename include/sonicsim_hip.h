@@ -141,6 +141,21 @@ int ss_convolve_moving_seg_div_f32(const float* x, int64_t T, const float* rirs,
 int ss_convolve_scene_f32(int32_t nsrc, const float* const* x, int64_t T, const float* const* rirs, const int32_t* P, int32_t C, int32_t L,
                           const int64_t* const* seg_len, const float* const* divisor, float* const* y, uint32_t flags, void* stream);
 
+/* ---- streaming render with persistent state (not in the reference, whose SonicSim_moving.py:98-125 renders a
+ * whole source at once).  ss_stream_open fixes the bank rirs[P][C][L] (DEVICE pointer, must stay valid and unchanged until close) and the
+ * schedule seg_len[P-1] (HOST, as in ss_convolve_moving_seg_f32; the total length is their sum).  ss_stream_push takes the next n dry
+ * samples (DEVICE) and writes their rendered audio out[C][n] (DEVICE) -- the same samples a one-piece ss_convolve_moving_seg_f32 render
+ * produces, to float32 round-off (the inverse transforms see differently grouped sums).  What persists between pushes, in HBM: the
+ * partition spectra of the filter rows the trajectory is between (each row is transformed once, a segment ahead of its use), the ring of
+ * input spectra of the completed 4096-sample blocks, the dry signal so far.  A push therefore costs one forward transform + two
+ * multiply-accumulate sweeps over ceil(L / 4096) partitions + two inverse transforms per channel, whatever L: one kernel launch per
+ * piece (a push is cut where it crosses a block of the global 4096-sample grid or a trajectory segment), no host synchronisation.
+ * ss_stream_info: {samples pushed, total, pushes, pieces (launches), filter rows transformed, bytes of persistent state}. */
+int ss_stream_open(void** handle, const float* rirs, int32_t P, int32_t C, int32_t L, const int64_t* seg_len, uint32_t flags, void* stream);
+int ss_stream_push(void* handle, const float* chunk, int64_t n, float* out, uint32_t flags, void* stream);
+int ss_stream_info(void* handle, int64_t* out, int32_t n);
+int ss_stream_close(void* handle);
+
 /* ---- row F: SonicSim_moving.py:47-61  convolve_fixed_receiver --------------------------------
  * y[c,t] = (x * h[c])[t], 0 <= t < T.   h[C][L]. Replaces scipy.signal.fftconvolve(...)[:, :T]. */
 int ss_convolve_fixed_f32(const float* x, int64_t T, const float* h, int32_t C, int32_t L, float* y,

@@ -54,6 +54,11 @@ _SIGS = {
     "ss_host_path_stats": (ctypes.c_int, [c_f64p, ctypes.c_int32]),
     "ss_host_alloc": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int64]),
     "ss_host_free": (ctypes.c_int, [ctypes.c_void_p]),
+    "ss_stream_open": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p,
+                                      ctypes.c_uint32, ctypes.c_void_p]),
+    "ss_stream_push": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p]),
+    "ss_stream_info": (ctypes.c_int, [ctypes.c_void_p, c_i64p, ctypes.c_int32]),
+    "ss_stream_close": (ctypes.c_int, [ctypes.c_void_p]),
     "ss_async_status": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "ss_plan_status_last": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "ss_convolve_moving_seg_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32,

@@ -15,6 +15,7 @@ import sys
 PKG = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(PKG, "csrc", "sonicsim_hip.hip")
 DEPS = [SRC, os.path.join(PKG, "csrc", "tvfir_core.h"), os.path.join(PKG, "csrc", "plan.h"), os.path.join(PKG, "csrc", "tvfir13.h"),
+        os.path.join(PKG, "csrc", "stream13.h"), os.path.join(PKG, "csrc", "hostpipe.h"),
         os.path.join(os.path.dirname(PKG), "include", "sonicsim_hip.h")]
 OUT = os.path.join(PKG, "lib", "libsonicsim_hip.so")
 ASM_GEN = os.path.join(os.path.dirname(PKG), "tools", "gen_asm", "os13.py")

@@ -24,6 +24,7 @@
 #include "../../include/sonicsim_hip.h"
 #include "plan.h"
 #include "tvfir_core.h"
+#include "stream13.h"
 
 // Tuning / experiment switches (SS_OS_GEOM, SS_HSACO, SS_TRACE_FILE, SS_HOP_RS, ...) exist only in the library the tools build with
 // -DSS_TUNING_KNOBS (sonicsim_amd/build.py::build_tuning, lib/libsonicsim_hip_tuning.so); the product library reads no environment variable.
@@ -110,6 +111,18 @@ __global__ __launch_bounds__(512, 2) void k_xspec13(const float* __restrict__ x,
     if (pok) plan_dst[pi] = pv;
     if (plan_src)       // (a plan larger than the grid's 8 KB per workgroup: the remainder in a strided loop)
         for (int i = pi + (int)gridDim.x * 512; i < plan_n16; i += (int)gridDim.x * 512) plan_dst[i] = plan_src[i];
+}
+
+// streaming render with persistent state (stream13.h): filter row -> partition spectra (grid NP x C); one piece of a push (grid C)
+__global__ __launch_bounds__(512, 2) void k_stream_rows(StreamDev a, int row) {
+    __shared__ __attribute__((aligned(16))) c32 smem[LDS13_C32];
+    DevEnv env{smem};
+    stream_row_body(env, a, row, (int)blockIdx.x, (int)blockIdx.y);
+}
+__global__ __launch_bounds__(512, 2) void k_stream_push(StreamDev a, StreamPiece pc) {
+    __shared__ __attribute__((aligned(16))) c32 smem[LDS13_C32];
+    DevEnv env{smem};
+    stream_push_body(env, a, pc, (int)blockIdx.x);
 }
 
 // the same for the sources of ONE scene launch (ss_convolve_scene_f32): blockIdx.y = source; every source has its own dry signal,
@@ -2332,6 +2345,129 @@ int ss_shutdown(void) {
 int ss_convolve_moving_f32(const float* x, int64_t T, const float* rirs, int32_t P, int32_t C, int32_t L, const int64_t* idx,
                            const float* w, float* y, uint32_t flags, void* stream) {
     return render(COEF_EXPLICIT, x, T, rirs, P, C, L, nullptr, idx, w, y, flags, stream);
+}
+
+// ---------------------------------------------------------------------------------------------
+// streaming render with persistent state (stream13.h)
+struct SsStream {
+    int device = -1;
+    StreamDev d{};
+    std::vector<int64_t> seg_start;      // [P], last == total
+    int64_t total = 0, pos = 0;
+    int k = 0;                           // current segment (monotone)
+    int slot_row[STREAM_ROW_SLOTS] = {-1, -1, -1, -1};
+    int64_t pushes = 0, pieces = 0, rows_prepared = 0;
+};
+
+static int stream_prepare_row(SsStream* st, int row, hipStream_t stream) {
+    if (row < 0 || row >= st->d.P) return SS_OK;
+    int& have = st->slot_row[row & (STREAM_ROW_SLOTS - 1)];
+    if (have == row) return SS_OK;
+    hipLaunchKernelGGL(k_stream_rows, dim3((unsigned)st->d.NP, (unsigned)st->d.C), dim3(NT13), 0, stream, st->d, row);
+    HIPCHK(hipGetLastError());
+    have = row;
+    ++st->rows_prepared;
+    return SS_OK;
+}
+
+int ss_stream_open(void** handle, const float* rirs, int32_t P, int32_t C, int32_t L, const int64_t* seg_len, uint32_t flags, void* stream_) {
+    if (!handle || !rirs || !seg_len) return fail(SS_EINVAL, "ss_stream_open: NULL argument");
+    if (!(flags & SS_FLAG_DEVICE_PTR)) return fail(SS_EINVAL, "ss_stream_open takes a DEVICE bank (SS_FLAG_DEVICE_PTR): the persistent state lives in HBM");
+    if (P < 2 || C < 1 || C > 65535 || L < 1) return fail(SS_EINVAL, "bad shape: P=%d C=%d L=%d (a moving source has at least 2 positions)", P, C, L);
+    Ctx* c;
+    int rc = get_ctx(&c);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(c->mu);
+    hipStream_t stream = (hipStream_t)stream_;
+    if ((rc = stream_enter(c, stream))) return rc;
+    SsStream* st = new SsStream();
+    st->device = c->device;
+    st->seg_start.resize((size_t)P);
+    int64_t acc = 0;
+    for (int k = 0; k < P - 1; ++k) {
+        if (seg_len[k] < 0) { delete st; return fail(SS_EINVAL, "seg_len[%d] = %lld is negative", k, (long long)seg_len[k]); }
+        st->seg_start[(size_t)k] = acc;
+        acc += seg_len[k];
+    }
+    st->seg_start[(size_t)P - 1] = acc;
+    st->total = acc;
+    StreamDev& d = st->d;
+    d.bank = rirs; d.P = P; d.C = C; d.L = L;
+    d.NP = (L + B13 - 1) / B13;
+    d.NR = d.NP + 1;
+    d.consts = c->consts13;
+    const size_t hs = sizeof(c32) * (size_t)STREAM_ROW_SLOTS * C * d.NP * B13, xr = sizeof(c32) * (size_t)d.NR * B13;
+    hipError_t e = hipMalloc((void**)&d.Hs, hs);
+    if (e == hipSuccess) e = hipMalloc((void**)&d.Xr, xr);
+    if (e == hipSuccess) e = hipMalloc((void**)&d.xh, sizeof(float) * (size_t)(acc > 0 ? acc : 1));
+    if (e != hipSuccess) {
+        if (d.Hs) hipFree(d.Hs);
+        if (d.Xr) hipFree(d.Xr);
+        delete st;
+        return fail(SS_ENOMEM, "ss_stream_open: %s", hipGetErrorString(e));
+    }
+    // the first segment's two rows, and the row after them, are transformed now; every later row one whole segment ahead of its use
+    for (int r = 0; r < 3; ++r)
+        if ((rc = stream_prepare_row(st, r, stream))) return rc;
+    *handle = st;
+    return SS_OK;
+}
+
+int ss_stream_push(void* handle, const float* chunk, int64_t n, float* out, uint32_t flags, void* stream_) {
+    SsStream* st = static_cast<SsStream*>(handle);
+    if (!st || (n > 0 && (!chunk || !out))) return fail(SS_EINVAL, "ss_stream_push: NULL argument");
+    if (!(flags & SS_FLAG_DEVICE_PTR)) return fail(SS_EINVAL, "ss_stream_push takes device pointers (SS_FLAG_DEVICE_PTR)");
+    if (n < 0 || st->pos + n > st->total) return fail(SS_EINVAL, "more input (%lld + %lld samples) than the trajectory schedule covers (%lld)",
+                                                       (long long)st->pos, (long long)n, (long long)st->total);
+    Ctx* c;
+    int rc = get_ctx(&c);
+    if (rc) return rc;
+    if (c->device != st->device) return fail(SS_EINVAL, "the stream was opened on device %d, the current device is %d", st->device, c->device);
+    std::lock_guard<std::mutex> lk(c->mu);
+    hipStream_t stream = (hipStream_t)stream_;
+    if ((rc = stream_enter(c, stream))) return rc;
+    ++st->pushes;
+    int64_t left = n, off = 0;
+    while (left > 0) {
+        int64_t len = 0;
+        if (!stream_next_piece(st->seg_start.data(), st->d.P, st->pos, left, st->k, len)) return fail(SS_EINVAL, "push past the end of the schedule");
+        for (int r = st->k; r <= st->k + 2; ++r)       // k, k + 1: needed now (prepared a segment ago unless the stream just started / jumped
+            if ((rc = stream_prepare_row(st, r, stream))) return rc;     // over empty segments); k + 2: for the next segment
+        StreamPiece pc;
+        pc.pos = st->pos; pc.n = (int32_t)len; pc.j = (int32_t)(st->pos / B13); pc.k = st->k;
+        pc.seg_start = st->seg_start[(size_t)st->k];
+        const int64_t nk = st->seg_start[(size_t)st->k + 1] - st->seg_start[(size_t)st->k];
+        pc.inv_len = nk > 0 ? 1.0 / (double)nk : 0.0;
+        pc.chunk = chunk + off; pc.out = out; pc.out_stride = n; pc.out_off = off;
+        hipLaunchKernelGGL(k_stream_push, dim3((unsigned)st->d.C), dim3(NT13), 0, stream, st->d, pc);
+        HIPCHK(hipGetLastError());
+        ++st->pieces;
+        st->pos += len; off += len; left -= len;
+    }
+    return SS_OK;
+}
+
+int ss_stream_info(void* handle, int64_t* out, int32_t n) {
+    SsStream* st = static_cast<SsStream*>(handle);
+    if (!st || !out) return fail(SS_EINVAL, "ss_stream_info: NULL argument");
+    const int64_t v[6] = {st->pos, st->total, st->pushes, st->pieces, st->rows_prepared,
+                          (int64_t)(sizeof(c32) * ((size_t)STREAM_ROW_SLOTS * st->d.C * st->d.NP + (size_t)st->d.NR) * B13 + sizeof(float) * (size_t)st->total)};
+    for (int i = 0; i < n && i < 6; ++i) out[i] = v[i];
+    return SS_OK;
+}
+
+int ss_stream_close(void* handle) {
+    SsStream* st = static_cast<SsStream*>(handle);
+    if (!st) return SS_OK;
+    int cur = -1;
+    (void)hipGetDevice(&cur);
+    if (cur != st->device) (void)hipSetDevice(st->device);
+    if (st->d.Hs) hipFree(st->d.Hs);          // (hipFree synchronises the device: no kernel of the stream is still reading)
+    if (st->d.Xr) hipFree(st->d.Xr);
+    if (st->d.xh) hipFree(st->d.xh);
+    if (cur >= 0 && cur != st->device) (void)hipSetDevice(cur);
+    delete st;
+    return SS_OK;
 }
 
 int ss_set_host_pipe(int threads, int64_t slot_bytes, int64_t chunk_bytes, int bind) {

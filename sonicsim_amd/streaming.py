@@ -9,8 +9,9 @@ filter rows of the trajectory segments that overlap [t0, t1) only (``SonicSim_mo
 * ``render_time_sharded``  the ranges [k T / world, (k + 1) T / world) snapped to segment boundaries, one per rank; rank 0 gathers the
                       pieces (``parallel.gather_to_root``).  No exchange during compute: x (3.8 MB at config 2) is replicated, the
                       bank rows partition with the segments (SURVEY 8e "finer-grained option").
-* ``StreamingRenderer``    push dry-signal chunks, get rendered chunks: keeps the last L - 1 input samples as history, so a 60 s render
-                      can be produced and consumed piecewise (online use, bounded latency, bounded output memory).
+* ``StreamingRenderer``    push dry-signal chunks, get rendered chunks.  Round 4: with PERSISTENT state in HBM (filter-row spectra, ring of
+                      input spectra, the dry signal so far: ``ss_stream_push``), a push costs O(chunk + L / 4096 partitions of spectra
+                      read from L2), not a re-render with L - 1 samples of history.
 
 The block grid of the overlap-save engine is anchored at the start of each rendered range, so a sharded / streamed render agrees with the
 one-piece render to float32 round-off (~3e-7 relative), not bit for bit; every piece is deterministic.
@@ -123,20 +124,59 @@ class StreamingRenderer:
 
         sr = StreamingRenderer(rirs, seg_len)             # rirs (P, C, L), seg_len (P-1,) with sum = total length
         for chunk in chunks_of_x:  y_chunk = sr.push(chunk)     # (C, len(chunk))
-    """
 
-    def __init__(self, rirs, seg_len, path=None):
-        self.rirs, self.seg_len, self.path = rirs, np.asarray(seg_len, dtype=np.int64), path
+    Device tensors (round 4): the engine with PERSISTENT state (``ss_stream_open`` / ``ss_stream_push``, csrc/stream13.h) -- the partition
+    spectra of the two filter rows the trajectory is between, the ring of input spectra of the completed blocks and the dry signal so far
+    stay in HBM, so a push costs one forward transform + two multiply-accumulate sweeps + two inverse transforms per channel whatever L
+    (one launch per piece, no host synchronisation), instead of re-rendering with the L - 1 samples of history as rounds 2-3 did.
+    Host arrays keep that older form (``engine="rerender"``: every push goes through ``render_range``)."""
+
+    def __init__(self, rirs, seg_len, path=None, engine=None):
+        import ctypes
+
+        from . import _lib
+        self.rirs, self.seg_len, self.path = rirs, np.ascontiguousarray(np.asarray(seg_len, dtype=np.int64)), path
         self.total = int(self.seg_len.sum())
         self.L = rirs.shape[2]
         self.pos = 0
-        self.hist = None                                            # the last L - 1 input samples
+        self.hist = None                                            # ("rerender" engine) the last L - 1 input samples
+        dev = ops._is_dev(rirs)
+        if engine is None:
+            engine = "persistent" if dev and path is None else "rerender"
+        if engine not in ("persistent", "rerender"):
+            raise ValueError("engine must be 'persistent' or 'rerender'")
+        if engine == "persistent" and not dev:
+            raise ValueError("the persistent-state engine needs a device bank (its state lives in HBM)")
+        self.engine = engine
+        self._h = None
+        if engine == "persistent":
+            import torch
+            if rirs.dim() != 3 or self.seg_len.shape != (rirs.shape[0] - 1,):
+                raise ValueError("shapes: rirs (P, C, L), seg_len (P-1,)")
+            self.rirs = ops._dev32(rirs, "rirs")                    # kept alive: the library reads the bank on every row change
+            P, C, L = (int(v) for v in self.rirs.shape)
+            self.C = C
+            h = ctypes.c_void_p()
+            ops._set_device(self.rirs)
+            cur = torch.cuda.current_device()
+            _lib.check(_lib.load().ss_stream_open(ctypes.byref(h), ops._ptr(self.rirs), P, C, L, self.seg_len.ctypes.data_as(_lib.c_i64p),
+                                                  _lib.FLAG_DEVICE_PTR, ops._stream_ptr(self.rirs)))
+            self._h = h
+            self._lib = _lib
 
     def push(self, chunk):
         import torch
         n = chunk.shape[-1]
         if self.pos + n > self.total:
             raise ValueError("more input than the trajectory schedule covers")
+        if self.engine == "persistent":
+            x = ops._dev32(torch.as_tensor(chunk).to(self.rirs.device), "chunk").reshape(-1)
+            out = torch.empty((self.C, n), dtype=torch.float32, device=self.rirs.device)
+            if n:
+                with torch.cuda.device(self.rirs.device):
+                    self._lib.check(self._lib.load().ss_stream_push(self._h, ops._ptr(x), n, ops._ptr(out), self._lib.FLAG_DEVICE_PTR, ops._stream_ptr(x)))
+            self.pos += n
+            return out
         is_t = torch.is_tensor(chunk)
         cat = (lambda a, b: torch.cat([a, b])) if is_t else (lambda a, b: np.concatenate([a, b]))
         buf = chunk if self.hist is None else cat(self.hist, chunk)
@@ -152,3 +192,23 @@ class StreamingRenderer:
         keep = min(self.L - 1, buf.shape[-1])
         self.hist = buf[buf.shape[-1] - keep:]
         return y
+
+    def info(self):
+        """persistent engine: {pos, total, pushes, pieces (kernel launches), rows_transformed, state_bytes}"""
+        import ctypes
+        if self._h is None:
+            return {"pos": self.pos, "total": self.total}
+        v = (ctypes.c_int64 * 6)()
+        self._lib.check(self._lib.load().ss_stream_info(self._h, v, 6))
+        return dict(zip(("pos", "total", "pushes", "pieces", "rows_transformed", "state_bytes"), (int(a) for a in v)))
+
+    def close(self):
+        if self._h is not None:
+            self._lib.load().ss_stream_close(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -10,6 +10,7 @@
 
 #include "../../sonicsim_amd/csrc/plan.h"
 #include "../../sonicsim_amd/csrc/tvfir_core.h"
+#include "../../sonicsim_amd/csrc/stream13.h"
 
 using namespace ss;
 
@@ -187,6 +188,55 @@ int emul_plan_compare(const int64_t* seg_len, int P, int C, int L, int64_t* nfas
     for (const Task& t : fast)
         for (int j = 0; j < t.nj; ++j) { Task u = t; u.j0 = t.j0 + j; if (!std::binary_search(gk.begin(), gk.end(), key(u))) return 5; }
     return 0;
+}
+
+// streaming render with persistent state (stream13.h): the kernel bodies and the host-side cut of a push into pieces, pushes of the
+// given sizes (the last push takes whatever is left); y[C][T].  Returns the number of pieces (kernel launches), < 0 on error.
+int emul_stream(const float* x, int64_t T, const float* bank, int P, int C, int L, const int64_t* seg_len, const int64_t* sizes, int nsizes, float* y) {
+    std::vector<int64_t> seg_start(P);
+    int64_t s = 0;
+    for (int k = 0; k < P - 1; ++k) { seg_start[k] = s; s += seg_len[k]; }
+    seg_start[P - 1] = s;
+    if (s != T) return -1;
+    std::vector<c32> c13;
+    build_consts13(c13);
+    StreamDev d;
+    d.bank = bank; d.P = P; d.C = C; d.L = L; d.NP = (L + B13 - 1) / B13; d.NR = d.NP + 1; d.consts = c13.data();
+    std::vector<c32> Hs((size_t)STREAM_ROW_SLOTS * C * d.NP * B13), Xr((size_t)d.NR * B13);
+    std::vector<float> xh((size_t)T);
+    d.Hs = Hs.data(); d.Xr = Xr.data(); d.xh = xh.data();
+    int slot_row[STREAM_ROW_SLOTS] = {-1, -1, -1, -1};
+    auto prepare = [&](int row) {
+        if (row < 0 || row >= P || slot_row[row & (STREAM_ROW_SLOTS - 1)] == row) return;
+        launch(d.NP * C, [&](HostEnv& env, int b) { stream_row_body(env, d, row, b % d.NP, b / d.NP); }, NT13);
+        slot_row[row & (STREAM_ROW_SLOTS - 1)] = row;
+    };
+    for (int r = 0; r < 3; ++r) prepare(r);
+    int64_t pos = 0;
+    int k = 0, pieces = 0;
+    for (int i = 0; pos < T; ++i) {
+        int64_t n = i < nsizes ? sizes[i] : T - pos;
+        if (n > T - pos) n = T - pos;
+        if (n <= 0) { if (i >= nsizes) break; continue; }
+        std::vector<float> out((size_t)C * n);
+        int64_t left = n, off = 0;
+        while (left > 0) {
+            int64_t len = 0;
+            if (!stream_next_piece(seg_start.data(), P, pos, left, k, len)) return -2;
+            for (int r = k; r <= k + 2; ++r) prepare(r);
+            StreamPiece pc;
+            pc.pos = pos; pc.n = (int32_t)len; pc.j = (int32_t)(pos / B13); pc.k = k;
+            pc.seg_start = seg_start[k];
+            const int64_t nk = seg_start[k + 1] - seg_start[k];
+            pc.inv_len = nk > 0 ? 1.0 / (double)nk : 0.0;
+            pc.chunk = x + pos; pc.out = out.data(); pc.out_stride = n; pc.out_off = off;
+            launch(C, [&](HostEnv& env, int c) { stream_push_body(env, d, pc, c); }, NT13);
+            ++pieces;
+            pos += len; off += len; left -= len;
+        }
+        for (int c = 0; c < C; ++c) std::memcpy(y + (int64_t)c * T + (pos - n), out.data() + (int64_t)c * n, sizeof(float) * (size_t)n);
+    }
+    return pieces;
 }
 
 // mode: 0 fixed (P==1), 1 seg (seg_len[P-1]), 2 explicit (idx,w).  path: 0 = overlap-save, 1 = direct

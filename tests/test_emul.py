@@ -20,7 +20,8 @@ def emul():
     src = os.path.join(HERE, "emul", "emul.cpp")
     out = os.path.join(HERE, "emul", "libss_emul.so")
     deps = [src, os.path.join(HERE, "..", "sonicsim_amd", "csrc", "tvfir_core.h"), os.path.join(HERE, "..", "sonicsim_amd", "csrc", "plan.h"),
-            os.path.join(HERE, "..", "sonicsim_amd", "csrc", "tvfir13.h")]
+            os.path.join(HERE, "..", "sonicsim_amd", "csrc", "tvfir13.h"),
+            os.path.join(HERE, "..", "sonicsim_amd", "csrc", "stream13.h")]
     if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
         subprocess.run(["g++", "-O2", "-std=c++20", "-shared", "-fPIC", "-pthread", src, "-o", out], check=True)
     return ctypes.CDLL(out)
@@ -246,3 +247,25 @@ def test_scene_planner_tiles_every_source(emul):
                             pos += nj
                         assert pos * B >= a2 and (pos - 1) * B < a2
             assert not seen
+
+
+def test_streaming_bodies_against_the_reference_algorithm(emul):
+    """round 4, row N4: the streaming engine with persistent state (stream13.h: filter-row spectra kept across pushes, ring of input
+    spectra, one forward + two inverse transforms per piece) -- its kernel bodies and its host-side cut of a push into pieces, run on
+    the CPU emulator for irregular push sizes incl. pushes that cross blocks and segments and a zero-length segment, against the
+    reference algorithm (oracle/moving.py)."""
+    from oracle import moving as O
+    rng = np.random.default_rng(11)
+    T, Pn, C, L = 13000, 6, 2, 9000                      # NP = 3 partitions, 4 blocks of 4096
+    x = rng.standard_normal(T).astype(np.float32)
+    bank = (rng.standard_normal((Pn, C, L)) * np.exp(-4.0 * np.arange(L) / L)).astype(np.float32)
+    seg = np.array([3000, 0, 4500, 2500, 3000], dtype=np.int64)
+    assert seg.sum() == T
+    idx, w = O.expand_segments(seg)
+    ref = O.convolve_moving_receiver(x, bank, idx, w)
+    for sizes in ([160] * 12 + [4000, 1, 5000], [T], [4096, 4096, 4096]):
+        sizes = np.asarray(sizes, dtype=np.int64)
+        y = np.full((C, T), np.nan, np.float32)
+        pieces = emul.emul_stream(P(x), ctypes.c_int64(T), P(bank), Pn, C, L, P(seg, ip), P(sizes, ip), len(sizes), P(y))
+        assert pieces >= len([n for n in sizes if n > 0])
+        assert_parity(y, ref, tol=2e-6)

@@ -67,6 +67,56 @@ def test_streaming_chunks(gpu):
     assert rel_rms(yh, full.cpu().numpy()) < 2e-6
 
 
+def test_persistent_state_engine(gpu):
+    """round 4: ss_stream_push keeps the filter-row spectra, the ring of input spectra and the dry signal in HBM.  Irregular pushes (one
+    sample, exactly one block, across several blocks and segments, a zero-length segment in the schedule), the older re-render engine on
+    the same chunks, the reference algorithm, bookkeeping of pieces / transformed rows, two renderers interleaved on one device."""
+    from sonicsim_amd import ops, streaming
+    sc, seg, bank, x = _scene(gpu, T=150000, P=12, C=3, L=30000)
+    seg = seg.copy()
+    seg[4] += seg[3]
+    seg[3] = 0                                                          # a position the source passes in no time
+    full = ops.convolve_moving_seg(x, bank, seg)
+    idx, w = moving.expand_segments(seg)
+    ref = moving.convolve_moving_receiver(sc.x, bank.cpu().numpy(), idx, w)
+    assert rel_rms(full.cpu().numpy(), ref) < 1e-6
+    rng = np.random.default_rng(8)
+    for sizes in ([160] * 300, [1, 4095, 4096, 4097, 20000, 1], list(rng.integers(1, 12000, size=30)), [sc.T]):
+        sr = streaming.StreamingRenderer(bank, seg)
+        assert sr.engine == "persistent"
+        old = streaming.StreamingRenderer(bank, seg, engine="rerender")
+        out, pos = [], 0
+        for n in sizes:
+            n = int(min(n, sc.T - pos))
+            if n == 0:
+                break
+            y = sr.push(x[pos:pos + n])
+            assert y.shape == (3, n)
+            if len(sizes) < 50:
+                yo = old.push(x[pos:pos + n])
+                assert float((y - yo).abs().max()) < 2e-5 * float(full.double().pow(2).mean().sqrt())
+            out.append(y)
+            pos += n
+        if pos < sc.T:
+            out.append(sr.push(x[pos:]))
+        y = torch.cat(out, dim=1)
+        assert rel_rms(y.cpu().numpy(), ref) < 2e-6 and rel_rms(y.cpu().numpy(), full.cpu().numpy()) < 2e-6
+        info = sr.info()
+        assert info["pos"] == sc.T == info["total"] and info["pieces"] >= info["pushes"] and info["rows_transformed"] == 12, info
+        with pytest.raises(ValueError):
+            sr.push(x[:1])
+        sr.close()
+    a, b = streaming.StreamingRenderer(bank, seg), streaming.StreamingRenderer(bank.flip(0).contiguous(), seg)
+    ya = torch.cat([a.push(x[:7000]), a.push(x[7000:30000])], dim=1)
+    yb = b.push(x[:30000])
+    ya2 = a.push(x[30000:50000])
+    assert float((torch.cat([ya, ya2], dim=1) - full[:, :50000]).abs().max()) < 2e-5 * float(full.double().pow(2).mean().sqrt())
+    fullb = ops.convolve_moving_seg(x, bank.flip(0).contiguous(), seg)
+    assert float((yb - fullb[:, :30000]).abs().max()) < 2e-5 * float(fullb.double().pow(2).mean().sqrt())
+    with pytest.raises(ValueError):
+        streaming.StreamingRenderer(bank.cpu().numpy(), seg, engine="persistent")
+
+
 def _sharded_worker(rank, world, port, config, q):
     """one of `world` processes that share cuda:0 over gloo (RCCL refuses two ranks on one device): its time slice of ONE render"""
     import os

@@ -22,11 +22,11 @@ seg = synth.scene_segments(sc, 0)
 bank, peak = ops.rir_bank_synth(sc.delay, sc.dgain, sc.L, sc.fs, sc.rt60, sc.bank_seed, device=dev, return_peak=True)
 ops.divide_by_(bank, peak)
 x = torch.from_numpy(sc.x).to(dev)
-for ms in (10, 40, 256):
+for eng, ms in [(e, m) for e in ("persistent", "rerender") for m in (10, 40, 256)]:
     n = sc.fs * ms // 1000
-    sr = streaming.StreamingRenderer(bank, seg)
+    sr = streaming.StreamingRenderer(bank, seg, engine=eng)
     pos = 0
-    for _ in range(400):                       # past the first L samples: full history
+    for _ in range(800):                       # past the first L samples: full history
         sr.push(x[pos:pos + n]); pos += n
         if pos >= 60000: break
     torch.cuda.synchronize()
@@ -37,4 +37,4 @@ for ms in (10, 40, 256):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / k
     lat0 = time.perf_counter(); y = sr.push(x[pos:pos + n]); torch.cuda.synchronize(); lat = time.perf_counter() - lat0; pos += n
-    print(f"chunk {ms:4d} ms ({n} samples): {dt * 1e6:7.1f} us per push back to back = {ms * 1e-3 / dt:6.1f}x real time; one push + synchronise {lat * 1e6:7.1f} us")
+    print(f"{eng:10s} chunk {ms:4d} ms ({n} samples): {dt * 1e6:7.1f} us per push back to back = {ms * 1e-3 / dt:6.1f}x real time; one push + synchronise {lat * 1e6:7.1f} us")
