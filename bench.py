@@ -545,7 +545,9 @@ def run_scenes(args, rank, local_rank, world, dev):
             spec = pl[j % len(pl)]
             out = sg.slot(j) if sg is not None else None
             sir, snr = draws(base + j)
-            gains.append(rend.render(spec, seed=base + j, sirs=sir, snr=snr, out=out)[1])      # (5,) float64 on the device: no wait per scene
+            has_next = j + 1 < k and not (sg is not None and sg.on and sg.scene(j + 1) is None)
+            nxt = (pl[(j + 1) % len(pl)], base + j + 1) if has_next and not os.environ.get("BENCH_NO_PREFETCH") else None
+            gains.append(rend.render(spec, seed=base + j, sirs=sir, snr=snr, out=out, next_scene=nxt)[1])      # (5,) float64 on the device: no wait per scene
             if sg is not None:
                 sg.submit(j)
         run.gains = A.lufs_gains_from_result(torch.stack(gains).cpu().numpy()) if gains else None    # every scene's five loudness gains reach the host inside the timed region
@@ -642,7 +644,7 @@ def run_scenes(args, rank, local_rank, world, dev):
         "config": {"workload": f"{args.config}: {total} independent SonicSet scenes, {per_rank} per GPU"
                                + (", the (C, T) mix of every scene gathered to rank 0 while the next scene renders" if gather else ""),
                    "scene": "K1 x 5 (3 banks of 200 positions + 2 static IRs, produced inside the timed region, peak normalisation deferred into "
-                            "the render), ONE ss_convolve_scene_f32 launch for the 3 moving + 2 static renders, ss_lufs_norm_batch_f32 (results stay on "
+                            "the render; the NEXT scene's five K1 launches run on a second stream beside this scene's loudness / mix kernels), ONE ss_convolve_scene_f32 launch for the 3 moving + 2 static renders, ss_lufs_norm_batch_f32 (results stay on "
                             "the device; all gains are fetched once, inside the timed region), ss_mix_f32",
                    "T": spec.T, "P": len(pool[0].speakers[0][3]) + 1, "C": spec.C, "L": spec.L, "fs": spec.fs, "scenes_total": total,
                    "dry_signal_pool": len(pool), "gather": gather, "distributed": args.dist_info,

@@ -109,7 +109,7 @@ inline void merge_lpt(Plan& plan, int NP, std::vector<Task>& out) {
     out.insert(out.end(), plan.tasks[1].begin(), plan.tasks[1].end());
     auto cost = [NP](const Task& t) {
         const int np_eff = std::min(NP, t.j0 + t.nj);
-        return (int64_t)np_eff * (10 + 2 * t.nj) + 12 * (int64_t)t.nj;
+        return (int64_t)task_cost(np_eff, t.nj);
     };
     std::stable_sort(out.begin(), out.end(), [&](const Task& a, const Task& b) { return cost(a) > cost(b); });
 }
@@ -122,7 +122,7 @@ inline void merge_lpt_xcd(Plan& plan, int NP, int groups, std::vector<Task>& out
     constexpr int MAXCOST = 4096;
     auto cost = [NP](const Task& t) {
         const int np_eff = std::min(NP, t.j0 + t.nj);
-        const int c = np_eff * (10 + 2 * t.nj) + 12 * t.nj;
+        const int c = task_cost(np_eff, t.nj);
         return c < MAXCOST ? c : MAXCOST - 1;
     };
     static thread_local std::vector<Task> byt, tmp;
@@ -199,7 +199,7 @@ inline void plan_seg_lpt(const std::vector<int64_t>& seg_start /*[P], last == T*
     constexpr int MAXCOST = 4096;
     auto cost = [NP, rs](int j0, int nj) {
         const int np_eff = std::min(NP, ((j0 + (1 << rs) - 1) >> rs) + nj);
-        const int c = np_eff * (10 + 2 * nj) + 12 * nj;
+        const int c = task_cost(np_eff, nj);
         return c < MAXCOST ? c : MAXCOST - 1;
     };
     if (groups > 1) {
@@ -326,7 +326,7 @@ struct SceneSrc {
 };
 inline void plan_scene_lpt(const SceneSrc* src, int nsrc, int64_t T, int C, int block, int jmax, int NP, std::vector<Task>& out, int groups,
                            int tail_pct, int32_t* main_out) {
-    auto cost = [NP](int j0, int nj) { return std::min(NP, j0 + nj) * (10 + 2 * nj) + 12 * nj; };
+    auto cost = [NP](int j0, int nj) { return task_cost(std::min(NP, j0 + nj), nj); };
     static thread_local std::vector<std::vector<Task>> q;
     static thread_local std::vector<Task> part;
     if (groups < 1) groups = 1;

@@ -226,7 +226,7 @@ __device__ inline int32_t ld_agent(const int32_t* p) { return __hip_atomic_load(
 
 __device__ inline int plan_cost(int NP, int j0, int nj) {
     const int np_eff = NP < j0 + nj ? NP : j0 + nj;
-    const int c = np_eff * (10 + 2 * nj) + 12 * nj;
+    const int c = task_cost(np_eff, nj);
     return c < 4096 ? c : 4095;
 }
 
@@ -1511,6 +1511,8 @@ struct Ctx {
     int ring_next = 0;
     hipStream_t last_stream = nullptr;
     bool have_last = false;
+    hipStream_t k1_stream = nullptr;      // the bank generator's own lane (it only touches WS_K1): see stream_enter_k1
+    bool have_k1 = false;
     bool prof = false;
     std::vector<EvPair> evs;
     int prof_every = 1;                    // ss_prof_enable(N > 1): time every N-th launch of each kind only
@@ -1607,6 +1609,16 @@ int stream_enter(Ctx* c, hipStream_t s) {
     if (c->have_last && c->last_stream != s) HIPCHK(hipStreamSynchronize(c->last_stream));
     c->last_stream = s;
     c->have_last = true;
+    return SS_OK;
+}
+
+// The bank generator with device-resident geometry touches no shared workspace but its own peak slots (WS_K1): it is ordered against
+// other generator launches only, so a scene pipeline can run the NEXT scene's generator on a second stream while the current scene's
+// loudness / mix kernels run on the first (pipeline.SceneRenderer, round 4) without the stream switch synchronising the device.
+int stream_enter_k1(Ctx* c, hipStream_t s) {
+    if (c->have_k1 && c->k1_stream != s) HIPCHK(hipStreamSynchronize(c->k1_stream));
+    c->k1_stream = s;
+    c->have_k1 = true;
     return SS_OK;
 }
 
@@ -2608,12 +2620,13 @@ static int rir_synth(const SsRirParams* p, float* bank, float* peak, uint32_t fl
     if (rc) return rc;
     std::lock_guard<std::mutex> lk(c->mu);
     hipStream_t stream = (hipStream_t)stream_;
-    if ((rc = stream_enter(c, stream))) return rc;
     const bool dev = (flags & SS_FLAG_DEVICE_PTR) != 0;
     const size_t pc = (size_t)p->P * p->C;
     const size_t meta = pc * (sizeof(int32_t) + sizeof(float));
     const bool meta_dev = (flags & SS_FLAG_META_DEVICE) != 0;      // delay / dgain already live in HBM (a scene generator keeps its geometry there)
     if (meta_dev && !dev) return fail(SS_EINVAL, "SS_FLAG_META_DEVICE needs SS_FLAG_DEVICE_PTR");
+    if (!(dev && meta_dev) && (rc = stream_enter(c, stream))) return rc;      // (staging buffers of the shared workspace)
+    if ((rc = stream_enter_k1(c, stream))) return rc;
     if (!meta_dev) {
         Pinned* pin;
         if ((rc = pinned_acquire(c, meta, &pin))) return rc;

@@ -68,6 +68,13 @@ struct Task {
     int32_t nj;     // number of blocks (1..JMAX; direct: 1)
 };
 
+// Cost of a task of the persistent single-launch engines in planner units (1 unit ~ 0.13 us on MI355X), for the LPT order and the
+// equal-cost time ranges of the XCD-aware plan: np_eff forward transforms, np_eff x nj block MACs, nj inverse transforms + outputs.
+// Round 4 tried the model FITTED to per-workgroup busy times of the assembly kernel (round 2, DESIGN.md section 6: 9 + 10 np + np nj / 2 +
+// 20 nj) in its place: no difference with the dynamic queues + shared tail (profiles/r04h: kernel median 169.4-170.0 vs 167.9-169.5 us at
+// config 2, 668-671 vs 666-670 us at config 5, three interleaved rounds) -- the queues absorb the model error.  The analytic form stays.
+SS_HD int task_cost(int np_eff, int nj) { return np_eff * (10 + 2 * nj) + 12 * nj; }
+
 enum CoefMode : int32_t { COEF_FIXED = 0, COEF_SEG = 1, COEF_EXPLICIT = 2 };
 
 struct RenderParams {

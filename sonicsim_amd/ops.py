@@ -382,10 +382,12 @@ def convolve_fixed(x, h, path=None, out=None):
 
 
 @_restores_device
-def rir_bank_synth(delay, dgain, L, fs, rt60, seed, tail_gain=0.05, rho=0.9, device=None, return_peak=False):
+def rir_bank_synth(delay, dgain, L, fs, rt60, seed, tail_gain=0.05, rho=0.9, device=None, return_peak=False, out=None, peak_out=None):
     """Row R: synthetic bank (P,C,L) float32.  device=None -> NumPy array; else torch tensor on it.
     return_peak=True -> (bank, peak): max |bank| tracked inside the generating kernel (row G's abs().max() without a second
-    pass) -- a one-element device tensor (no synchronisation) or a Python float for the NumPy form."""
+    pass) -- a one-element device tensor (no synchronisation) or a Python float for the NumPy form.
+    out / peak_out (device form): caller-owned buffers to fill instead of fresh tensors.  With device-resident geometry the generator
+    is ordered only against other generator launches, so it may run on a second stream beside other kernels of this library."""
     lib = _lib.load()
     meta_dev = _is_dev(delay) and _is_dev(dgain)
     if meta_dev:
@@ -421,10 +423,20 @@ def rir_bank_synth(delay, dgain, L, fs, rt60, seed, tail_gain=0.05, rho=0.9, dev
         return bank
     import torch
     dev = torch.device(device)
-    bank = torch.empty((P, C, int(L)), dtype=torch.float32, device=dev)
+    if out is not None:        # a caller-owned bank buffer (a scene pipeline double-buffers its banks): contiguous float32 (P, C, L) on the device
+        if not (_is_dev(out) and out.dtype == torch.float32 and tuple(out.shape) == (P, C, int(L)) and out.is_contiguous() and out.device == dev):
+            raise ValueError("out must be a contiguous float32 device tensor of shape (P, C, L)")
+        bank = out
+    else:
+        bank = torch.empty((P, C, int(L)), dtype=torch.float32, device=dev)
     _set_device(bank)
     if return_peak:
-        peak = torch.empty(1, dtype=torch.float32, device=dev)
+        if peak_out is not None:
+            if not (_is_dev(peak_out) and peak_out.dtype == torch.float32 and peak_out.numel() == 1 and peak_out.device == dev):
+                raise ValueError("peak_out must be a one-element float32 tensor on the bank's device")
+            peak = peak_out
+        else:
+            peak = torch.empty(1, dtype=torch.float32, device=dev)
         _lib.check(lib.ss_rir_bank_synth_peak_f32(ctypes.byref(prm), _ptr(bank), _ptr(peak), _lib.FLAG_DEVICE_PTR | mflag, _stream_ptr(bank)))
         return bank, peak
     _lib.check(lib.ss_rir_bank_synth_f32(ctypes.byref(prm), _ptr(bank), _lib.FLAG_DEVICE_PTR | mflag, _stream_ptr(bank)))

@@ -117,30 +117,90 @@ def make_scene_spec(device, scene=0, config="cfg2") -> SceneSpec:
 class SceneRenderer:
     """Renders SceneSpecs with a reused stem stack (5, C, T).  one_launch=True (default): the five banks / IRs of the scene are produced
     first and all five renders run as ONE persistent launch; False: render by render, the three speakers' banks reuse one block of the
-    caching allocator one after the other."""
+    caching allocator one after the other.
+
+    Round 4 -- the provider of the NEXT scene runs beside the loudness / mix kernels of the current one: ``render(spec, seed, ...,
+    next_scene=(spec2, seed2))`` enqueues the five K1 launches of scene 2 on a second HIP stream right behind scene 1's render launch
+    (which needs every CU to itself) -- they fill the GPU while scene 1's loudness and mix kernels, short and latency bound, run on the
+    first stream -- into the other half of a double-buffered set of banks; the following ``render(spec2, seed2)`` finds them ready.
+    Same kernels, same bits; a scene whose banks were not prefetched generates them in line as before."""
 
     def __init__(self, spec: SceneSpec, device, one_launch=True):
         import torch
         self.device = device
         self.one_launch = one_launch          # all five renders of a scene in ONE persistent launch (bit-identical to the separate calls)
         self.stack = torch.empty((5, spec.C, spec.T), dtype=torch.float32, device=device)
+        self._k1_stream = None                # created on first use
+        self._sets = [None, None]             # double-buffered banks + peaks: set i = ([banks], [peaks])
+        self._set_next = 0
+        self._ready = None                    # (key, set index, event) of the prefetched scene
+        self._set_free = [None, None]         # event after which set i may be overwritten (its render has finished)
 
-    def render(self, spec: SceneSpec, seed: int, sirs=(0.0,), snr=15.0, out=None, sync=False):
+    # ---- the provider (K1 x 5) of one scene into bank set `si`
+    def _provide(self, spec, seed, si):
+        import torch
+        P = int(spec.speakers[0][1].shape[0])
+        if self._sets[si] is None or self._sets[si][0][0].shape != (P, spec.C, spec.L):
+            banks = [torch.empty((P, spec.C, spec.L), dtype=torch.float32, device=self.device) for _ in range(3)] + \
+                    [torch.empty((1, spec.C, spec.L), dtype=torch.float32, device=self.device) for _ in range(2)]
+            peaks = [torch.empty(1, dtype=torch.float32, device=self.device) for _ in range(3)]
+            self._sets[si] = (banks, peaks)
+        banks, peaks = self._sets[si]
+        for k, (x, delay, dgain, seg, rt60) in enumerate(spec.speakers):
+            ops.rir_bank_synth(delay, dgain, spec.L, spec.fs, rt60, (seed * 8 + k) & 0x7FFFFFFF, device=self.device, return_peak=True,
+                               out=banks[k], peak_out=peaks[k])
+        for k, (x, delay, dgain, rt60) in enumerate(spec.statics):
+            ops.rir_bank_synth(delay, dgain, spec.L, spec.fs, rt60, (seed * 8 + 4 + k) & 0x7FFFFFFF, device=self.device, out=banks[3 + k])
+        return banks, peaks
+
+    def prefetch(self, spec: SceneSpec, seed: int):
+        """Enqueue the provider of (spec, seed) on the side stream, behind everything enqueued so far on the current stream."""
+        import torch
+        if not (self.one_launch and spec.L > 4096):
+            return
+        if self._k1_stream is None:
+            self._k1_stream = torch.cuda.Stream(device=self.device)
+        si = self._set_next
+        self._set_next ^= 1
+        cur = torch.cuda.current_stream(self.device)
+        self._k1_stream.wait_stream(cur)                           # behind the current scene's render launch
+        if self._set_free[si] is not None:
+            self._k1_stream.wait_event(self._set_free[si])
+        with torch.cuda.stream(self._k1_stream):
+            self._provide(spec, seed, si)
+            ev = torch.cuda.Event()
+            ev.record(self._k1_stream)
+        self._ready = ((id(spec), int(seed)), si, ev)
+
+    def render(self, spec: SceneSpec, seed: int, sirs=(0.0,), snr=15.0, out=None, sync=False, next_scene=None):
         """K1 x 3 (bank + tracked peak) -> moving renders with the normalisation deferred; K1 x 2 -> static renders; loudness of
         the five stems in one call; mix of speakers {1, 2} + noise into ``out`` (or a fresh tensor).  Returns (mix, gains).
         sync=False (default): nothing in a scene waits for the GPU -- the five loudness gains are a float64 device tensor the caller
-        reads when it writes the scene's metadata; sync=True returns them as Python floats (one synchronisation per scene)."""
+        reads when it writes the scene's metadata; sync=True returns them as Python floats (one synchronisation per scene).
+        next_scene = (spec, seed) of the scene rendered next: its provider runs on the side stream beside this scene's loudness / mix."""
+        import torch
         if self.one_launch and spec.L > 4096:
-            # the provider first (five K1 launches), then ALL five renders in one persistent launch (ss_convolve_scene_f32)
-            xs, banks, segs, peaks = [], [], [], []
-            for k, (x, delay, dgain, seg, rt60) in enumerate(spec.speakers):
-                bank, peak = ops.rir_bank_synth(delay, dgain, spec.L, spec.fs, rt60, (seed * 8 + k) & 0x7FFFFFFF, device=self.device, return_peak=True)
-                xs.append(x); banks.append(bank); segs.append(seg); peaks.append(peak)
-            for k, (x, delay, dgain, rt60) in enumerate(spec.statics):
-                h = ops.rir_bank_synth(delay, dgain, spec.L, spec.fs, rt60, (seed * 8 + 4 + k) & 0x7FFFFFFF, device=self.device)
-                xs.append(x); banks.append(h); segs.append(None); peaks.append(None)
-            ops.convolve_scene(xs, banks, segs, peaks=peaks, outs=[self.stack[i] for i in range(len(xs))])
-            del banks
+            # the provider first (five K1 launches, or the prefetched set), then ALL five renders in one persistent launch (ss_convolve_scene_f32)
+            cur = torch.cuda.current_stream(self.device)
+            if self._ready is not None and self._ready[0] == (id(spec), int(seed)):
+                _, si, ev = self._ready
+                self._ready = None
+                cur.wait_event(ev)
+                banks, peaks = self._sets[si]
+            else:
+                si = self._set_next
+                self._set_next ^= 1
+                if self._set_free[si] is not None:
+                    cur.wait_event(self._set_free[si])
+                banks, peaks = self._provide(spec, seed, si)
+            xs = [sp[0] for sp in spec.speakers] + [st[0] for st in spec.statics]
+            segs = [sp[3] for sp in spec.speakers] + [None, None]
+            ops.convolve_scene(xs, banks, segs, peaks=list(peaks) + [None, None], outs=[self.stack[i] for i in range(len(xs))])
+            done = torch.cuda.Event()
+            done.record(cur)
+            self._set_free[si] = done                               # the set may be refilled once this render has finished
+            if next_scene is not None:
+                self.prefetch(*next_scene)
         else:
             i = 0
             for k, (x, delay, dgain, seg, rt60) in enumerate(spec.speakers):

@@ -178,7 +178,7 @@ int emul_plan_compare(const int64_t* seg_len, int P, int C, int L, int64_t* nfas
             if (covered[(size_t)r * C + c] != std::max<int64_t>(0, a2 - a0)) return 3;
     }
     // descending cost order
-    auto cost = [NP](const Task& t) { const int np_eff = std::min(NP, t.j0 + t.nj); return np_eff * (10 + 2 * t.nj) + 12 * t.nj; };
+    auto cost = [NP](const Task& t) { const int np_eff = std::min(NP, t.j0 + t.nj); return task_cost(np_eff, t.nj); };
     for (size_t i = 1; i < fast.size(); ++i)
         if (cost(fast[i]) > cost(fast[i - 1])) return 4;
     // the generic plan covers a superset of (row, chan, block) pairs

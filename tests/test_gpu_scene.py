@@ -101,3 +101,35 @@ def test_two_host_threads_on_their_own_streams(gpu):
     for t in threads:
         t.join()
     assert not errors, errors[:5]
+
+
+def test_scene_renderer_prefetched_provider_same_bits(gpu):
+    """round 4: the NEXT scene's five K1 launches run on a second stream beside the current scene's loudness / mix kernels
+    (double-buffered banks).  Same mixes and gains, bit for bit, as the in-line form -- also when a prefetched scene is skipped or a
+    scene arrives that was not announced."""
+    from sonicsim_amd import SonicSim_audio as A
+    from sonicsim_amd import pipeline
+    specs = [pipeline.make_scene_spec(gpu, scene=s, config="tiny") for s in range(3)]
+    order = [(0, 11), (1, 12), (2, 13), (0, 14), (1, 15)]
+
+    def run(prefetch, announce=None):
+        r = pipeline.SceneRenderer(specs[0], gpu)
+        outs = []
+        for i, (si, seed) in enumerate(order):
+            np.random.seed(100 + i)                                   # the loudness targets come from the global NumPy stream
+            nxt = None
+            if prefetch and i + 1 < len(order):
+                a = order[i + 1] if announce is None else announce[i]
+                nxt = (specs[a[0]], a[1]) if a is not None else None
+            mix, gains = r.render(specs[si], seed=seed, sirs=(1.5,), snr=12.0, next_scene=nxt)
+            outs.append((mix.clone(), gains.clone()))
+        torch.cuda.synchronize()
+        return outs
+
+    base = run(False)
+    for variant in (run(True), run(True, announce=[(1, 12), (0, 99), None, (1, 15), None])):   # a wrong announcement, a missing one
+        for (m0, g0), (m1, g1) in zip(base, variant):
+            assert torch.equal(m0, m1) and torch.equal(g0, g1)
+    assert all(torch.isfinite(m).all() for m, _ in base) and float(base[0][0].abs().max()) > 0
+    g = A.lufs_gains_from_result(base[0][1].cpu().numpy())
+    assert len(g) == 5
