@@ -547,7 +547,7 @@ def run_scenes(args, rank, local_rank, world, dev):
             sir, snr = draws(base + j)
             has_next = j + 1 < k and not (sg is not None and sg.on and sg.scene(j + 1) is None)
             nxt = (pl[(j + 1) % len(pl)], base + j + 1) if has_next and not os.environ.get("BENCH_NO_PREFETCH") else None
-            gains.append(rend.render(spec, seed=base + j, sirs=sir, snr=snr, out=out, next_scene=nxt)[1])      # (5,) float64 on the device: no wait per scene
+            gains.append(rend.render(spec, seed=base + j, sirs=sir, snr=snr, out=out, sync=False, next_scene=nxt)[1])      # (5,) float64 on the device: no wait per scene
             if sg is not None:
                 sg.submit(j)
         run.gains = A.lufs_gains_from_result(torch.stack(gains).cpu().numpy()) if gains else None    # every scene's five loudness gains reach the host inside the timed region
@@ -579,7 +579,7 @@ def run_scenes(args, rank, local_rank, world, dev):
             for s in sorted(set([ranges[r][0], ranges[r][-1]])):
                 j = s - ranges[r][0]
                 sir, snr = draws(s)
-                mix, _ = rend.render(plr[j % len(plr)], seed=s, sirs=sir, snr=snr)
+                mix, _ = rend.render(plr[j % len(plr)], seed=s, sirs=sir, snr=snr, sync=False)
                 checked.append(int(s))
                 if not torch.equal(mix, res[s]):
                     bad.append(int(s))

@@ -184,6 +184,12 @@ int ss_rir_bank_synth_f32(const SsRirParams* prm, float* bank, uint32_t flags, v
  * (device float: no synchronisation; host float: returned with the bank). */
 int ss_rir_bank_synth_peak_f32(const SsRirParams* prm, float* bank, float* peak, uint32_t flags, void* stream);
 
+/* The banks of one scene in ONE launch (SonicSet.py:61-63 generate_rir_combination x 3, :86-91 render_ir x 2): prm[n] (HOST array of n <= 8
+ * parameter records), banks[n] / peaks[n] (HOST arrays of DEVICE pointers; peaks or an entry may be NULL).  Needs SS_FLAG_DEVICE_PTR |
+ * SS_FLAG_META_DEVICE; banks that share C * L (even L, 16-byte aligned) run as one grid of (workgroups x banks), anything else falls back
+ * to n launches.  Same values as ss_rir_bank_synth_peak_f32 bank by bank. */
+int ss_rir_bank_synth_batch_f32(int32_t n, const SsRirParams* prm, float* const* banks, float* const* peaks, uint32_t flags, void* stream);
+
 /* ---- row G: SonicSim-SonicSet/SonicSim_audio.py:398  ir_output /= ir_output.abs().max() -------
  * In-place global peak normalisation (IEEE float32 division, bit-exact with the reference's
  * elementwise true division).  peak_out (HOST pointer, may be NULL) receives the peak; asking for

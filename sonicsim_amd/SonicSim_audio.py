@@ -196,7 +196,6 @@ def get_lufs_norm_audio_batch(stems, sr=16000, lufs=(-6,), allow_many_channels: 
     block_size = 0.4 if T / sr >= 0.4 else T / sr
     _, lo, hi, weights, _ = _meter_args(stems[0], sr, block_size, allow_many_channels, True)
     if not sync:
-        import torch
         out, res = ops.lufs_norm(stems, _kw_coef(float(sr)), lo, hi, block_size * sr, weights, targets, layout_tc=False, result_device=True)
         return out, res                 # (S, 4) float64 on the device: {loudness, linear gain, sum(out), sum(in)}; see lufs_gains_from_result
     out, loud, _lin, n, d = ops.lufs_norm(stems, _kw_coef(float(sr)), lo, hi, block_size * sr, weights, targets, layout_tc=False)

@@ -68,6 +68,8 @@ _SIGS = {
     "ss_rir_bank_synth_f32": (ctypes.c_int, [ctypes.POINTER(SsRirParams), ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p]),
     "ss_rir_bank_synth_peak_f32": (ctypes.c_int, [ctypes.POINTER(SsRirParams), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32,
                                                   ctypes.c_void_p]),
+    "ss_rir_bank_synth_batch_f32": (ctypes.c_int, [ctypes.c_int32, ctypes.POINTER(SsRirParams), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32,
+                                                   ctypes.c_void_p]),
     "ss_peak_normalize_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, c_f32p, ctypes.c_uint32, ctypes.c_void_p]),
     "ss_divide_by_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p]),
     "ss_convolve_moving_seg_div_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32,

@@ -434,9 +434,9 @@ __device__ __forceinline__ void box_muller2(uint32_t a, float& g0, float& g1) {
 // unrolled by two (two positions' hash / Box-Muller chains in flight per thread).
 // peak_bits (may be null): max |bank| over the whole bank -- row G's abs().max() for free; slots: 1 + gridDim.x words of workspace.
 template <bool FAST32, int V>
-__global__ __launch_bounds__(256) void k_rir_synth(RirDev p, float* __restrict__ bank, unsigned int* __restrict__ peak_bits,
-                                                   unsigned int* __restrict__ slots) {
-    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * V;
+__device__ __forceinline__ void rir_synth_body(const RirDev& p, float* __restrict__ bank, unsigned int* __restrict__ peak_bits,
+                                               unsigned int* __restrict__ slots, const unsigned bx, const unsigned gx) {
+    const int64_t i = ((int64_t)bx * 256 + threadIdx.x) * V;
     const int64_t CL = (int64_t)p.C * p.L;
     const bool live = i < CL;
     const int64_t ii = live ? i : CL - V;
@@ -511,17 +511,17 @@ __global__ __launch_bounds__(256) void k_rir_synth(RirDev p, float* __restrict__
         __syncthreads();
         if (threadIdx.x == 0) {
             const float m = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
-            __hip_atomic_store(slots + 1 + blockIdx.x, __float_as_uint(m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(slots + 1 + bx, __float_as_uint(m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const unsigned t = __hip_atomic_fetch_add(slots, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            is_last = t == gridDim.x - 1;
+            is_last = t == gx - 1;
         }
         __syncthreads();
         if (is_last) {
             if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             __syncthreads();
             unsigned m = 0;
-            for (unsigned b = threadIdx.x; b < gridDim.x; b += 256) {
+            for (unsigned b = threadIdx.x; b < gx; b += 256) {
                 const unsigned v = __hip_atomic_load(slots + 1 + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 m = v > m ? v : m;                 // non-negative floats order like their bit patterns
             }
@@ -535,6 +535,26 @@ __global__ __launch_bounds__(256) void k_rir_synth(RirDev p, float* __restrict__
             }
         }
     }
+}
+
+template <bool FAST32, int V>
+__global__ __launch_bounds__(256) void k_rir_synth(RirDev p, float* __restrict__ bank, unsigned int* __restrict__ peak_bits,
+                                                   unsigned int* __restrict__ slots) {
+    rir_synth_body<FAST32, V>(p, bank, peak_bits, slots, blockIdx.x, gridDim.x);
+}
+
+// the banks of ONE scene in one launch (SonicSet.py:61-63 + :86-91: three trajectories + two static positions): blockIdx.y = bank.  All
+// banks share C * L (so one grid width fits them all); P, geometry, seed, decay, peak word and peak slots are per bank.
+struct RirBatch {
+    RirDev p[8];
+    float* bank[8];
+    unsigned int* peak[8];
+    unsigned int* slots[8];
+};
+template <int V>
+__global__ __launch_bounds__(256) void k_rir_synth_batch(RirBatch tab) {
+    const int b = (int)blockIdx.y;
+    rir_synth_body<true, V>(tab.p[b], tab.bank[b], tab.peak[b], tab.slots[b], blockIdx.x, gridDim.x);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1511,6 +1531,7 @@ struct Ctx {
     int ring_next = 0;
     hipStream_t last_stream = nullptr;
     bool have_last = false;
+    size_t k1_batch_per = 0;              // slot words per bank of the batched generator's layout in WS_K1 (0: the single-bank layout)
     hipStream_t k1_stream = nullptr;      // the bank generator's own lane (it only touches WS_K1): see stream_enter_k1
     bool have_k1 = false;
     bool prof = false;
@@ -2678,6 +2699,7 @@ static int rir_synth(const SsRirParams* p, float* bank, float* peak, uint32_t fl
             HIPCHK(hipMemsetAsync(c->ws[WS_K1], 0, sizeof(unsigned int), stream));
         }
         slots = (unsigned int*)c->ws[WS_K1];
+        c->k1_batch_per = 0;               // (the batched form lays its tickets out differently: it re-zeroes them when it runs next)
     }
     if (fast32 && vec4) hipLaunchKernelGGL((k_rir_synth<true, 4>), grid, dim3(256), 0, stream, d, dbank, dpeak, slots);
     else if (fast32 && vec2) hipLaunchKernelGGL((k_rir_synth<true, 2>), grid, dim3(256), 0, stream, d, dbank, dpeak, slots);
@@ -2695,6 +2717,68 @@ static int rir_synth(const SsRirParams* p, float* bank, float* peak, uint32_t fl
 }
 
 int ss_rir_bank_synth_f32(const SsRirParams* p, float* bank, uint32_t flags, void* stream) { return rir_synth(p, bank, nullptr, flags, stream); }
+
+int ss_rir_bank_synth_batch_f32(int32_t n, const SsRirParams* prm, float* const* banks, float* const* peaks, uint32_t flags, void* stream_) {
+    if (n < 1 || n > 8 || !prm || !banks) return fail(SS_EINVAL, "ss_rir_bank_synth_batch_f32: 1..8 banks");
+    const uint32_t need = SS_FLAG_DEVICE_PTR | SS_FLAG_META_DEVICE;
+    if ((flags & need) != need) return fail(SS_EINVAL, "the batched generator takes device banks and device-resident geometry (SS_FLAG_DEVICE_PTR | SS_FLAG_META_DEVICE)");
+    const int64_t CL = (int64_t)prm[0].C * prm[0].L;
+    bool one_launch = CL % 2 == 0;
+    for (int b = 0; b < n; ++b) {
+        const SsRirParams& p = prm[b];
+        if (!banks[b] || !p.delay || !p.dgain) return fail(SS_EINVAL, "bank %d: NULL pointer", b);
+        if (p.P < 1 || p.C < 1 || p.L < 1 || !(p.fs > 0) || !(p.rt60 > 0) || !(p.rho >= 0.0f && p.rho < 1.0f)) return fail(SS_EINVAL, "bank %d: bad RIR parameters", b);
+        if ((int64_t)p.C * p.L != CL || p.L % 2 != 0) one_launch = false;
+        if ((uint64_t)p.P * (uint64_t)CL >= ((uint64_t)1 << 33)) one_launch = false;            // the 32-bit pair counter of the fast path
+        if (((uintptr_t)banks[b] & 15) != 0) one_launch = false;
+    }
+    if (!one_launch) {      // shapes the one-launch form does not cover: bank by bank (same values either way)
+        for (int b = 0; b < n; ++b) {
+            const int rc = rir_synth(&prm[b], banks[b], peaks ? peaks[b] : nullptr, flags, stream_);
+            if (rc) return rc;
+        }
+        return SS_OK;
+    }
+    Ctx* c;
+    int rc = get_ctx(&c);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(c->mu);
+    hipStream_t stream = (hipStream_t)stream_;
+    if ((rc = stream_enter_k1(c, stream))) return rc;
+    // the widest form every bank admits (the same choice rir_synth makes for one bank: values do not depend on it)
+    bool all4 = true;
+    for (int b = 0; b < n; ++b) all4 = all4 && prm[b].L % 4 == 0;
+    const bool vec4 = all4 && CL / 4 / 64 >= (int64_t)c->num_cu * 32;
+    const unsigned gx = (unsigned)((CL / (vec4 ? 4 : 2) + 255) / 256);
+    const size_t per = (size_t)gx + 1, needw = sizeof(unsigned int) * per * 8;
+    if (c->ws_cap[WS_K1] < needw) {
+        if ((rc = ws_ensure(c, WS_K1, needw))) return rc;
+        HIPCHK(hipMemsetAsync(c->ws[WS_K1], 0, needw, stream));      // the arrival tickets (word 0 of every bank's slot block) start at 0
+        c->k1_batch_per = per;
+    } else if (c->k1_batch_per != per) {                             // another slot layout was in use: its tickets sit elsewhere
+        HIPCHK(hipMemsetAsync(c->ws[WS_K1], 0, c->ws_cap[WS_K1] < needw ? c->ws_cap[WS_K1] : needw, stream));
+        c->k1_batch_per = per;
+    }
+    RirBatch tab;
+    memset(&tab, 0, sizeof(tab));
+    for (int b = 0; b < n; ++b) {
+        const SsRirParams& p = prm[b];
+        RirDev& d = tab.p[b];
+        d.P = p.P; d.C = p.C; d.L = p.L;
+        d.tail_gain = p.tail_gain; d.rho = p.rho;
+        d.srho = (float)std::sqrt(1.0 - (double)p.rho * (double)p.rho);
+        d.inv_tau = 6.91 / ((double)p.rt60 * (double)p.fs);
+        d.seed = p.seed;
+        d.delay = p.delay; d.dgain = p.dgain;
+        tab.bank[b] = banks[b];
+        tab.peak[b] = (peaks && peaks[b]) ? reinterpret_cast<unsigned int*>(peaks[b]) : nullptr;
+        tab.slots[b] = (unsigned int*)c->ws[WS_K1] + per * (size_t)b;
+    }
+    if (vec4) hipLaunchKernelGGL((k_rir_synth_batch<4>), dim3(gx, (unsigned)n), dim3(256), 0, stream, tab);
+    else hipLaunchKernelGGL((k_rir_synth_batch<2>), dim3(gx, (unsigned)n), dim3(256), 0, stream, tab);
+    HIPCHK(hipGetLastError());
+    return SS_OK;
+}
 
 int ss_rir_bank_synth_peak_f32(const SsRirParams* p, float* bank, float* peak, uint32_t flags, void* stream) {
     if (!peak) return fail(SS_EINVAL, "peak is NULL");

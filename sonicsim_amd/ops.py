@@ -153,7 +153,8 @@ def _out_ct(out, C, T, dev):
 def convolve_moving(x, rirs, idx, w, path=None, out=None, validate=True):
     """Row V (SonicSim_moving.py:63-96).  x (T,), rirs (P,C,L), idx (T,) int, w (T,) -> (C,T).
     validate=False (device tensors, assembly engine): the schedule is planned on the device and the call only enqueues work --
-    no host synchronisation; an out-of-range interp_index is then reported by ``async_status()`` instead of a ValueError here."""
+    no host synchronisation; an out-of-range interp_index is then reported by ``async_status()`` instead of a ValueError here.
+    A caller-supplied ``out`` is written before the schedule has been validated: when this raises, its contents are NaN / undefined."""
     lib = _lib.load()
     flags = PATHS[path]
     if _is_dev(x) or _is_dev(rirs):
@@ -182,7 +183,15 @@ def convolve_moving(x, rirs, idx, w, path=None, out=None, validate=True):
             if oor.value < 0:
                 return y                          # the library ignored the flag (another engine): it validated on the host before rendering
             if oor.value or irregular.value:
-                async_status(x)                   # (this call also latched its error for ss_async_status pollers: clear it, it is reported here)
+                # this call also latched its error for ss_async_status pollers: clear it, it is reported here.  The latch is per device and
+                # first-error-wins, so what comes back may be an OLDER error of an unpolled validate=False render: that one is not ours to
+                # swallow -- hand it on as a warning instead of dropping it
+                code, wh = async_status(x)
+                mine = (1, int(where.value)) if oor.value else (2, None)
+                if code and (code != mine[0] or (mine[1] is not None and wh != mine[1])):
+                    import warnings
+                    warnings.warn(f"an earlier render with validate=False on this device had latched an error (code {code}, where {wh}) that "
+                                  "nobody polled with async_status(); it was cleared by this validating call", RuntimeWarning, stacklevel=3)
             if oor.value:
                 raise ValueError(f"interp_index out of range [0, {P - 2}] near sample {where.value} (the output buffer holds no valid render)")
             if not irregular.value:
@@ -441,6 +450,40 @@ def rir_bank_synth(delay, dgain, L, fs, rt60, seed, tail_gain=0.05, rho=0.9, dev
         return bank, peak
     _lib.check(lib.ss_rir_bank_synth_f32(ctypes.byref(prm), _ptr(bank), _lib.FLAG_DEVICE_PTR | mflag, _stream_ptr(bank)))
     return bank
+
+
+@_restores_device
+def rir_bank_synth_batch(geoms, L, fs, outs, peaks=None, tail_gain=0.05, rho=0.9):
+    """Row R for the banks of one scene in ONE launch (``ss_rir_bank_synth_batch_f32``).  geoms: list of (delay, dgain, rt60, seed) with
+    delay / dgain contiguous int32 / float32 (P_i, C) DEVICE tensors; outs[i]: contiguous float32 (P_i, C, L) device tensor to fill;
+    peaks[i]: one-element float32 device tensor or None.  Same values as ``rir_bank_synth`` bank by bank."""
+    import torch
+    n = len(geoms)
+    if not (1 <= n <= 8) or len(outs) != n or (peaks is not None and len(peaks) != n):
+        raise ValueError("1..8 banks, one output (and optionally one peak) per bank")
+    dev = outs[0].device
+    prm = (_lib.SsRirParams * n)()
+    for i, (delay, dgain, rt60, seed) in enumerate(geoms):
+        if not (_is_dev(delay) and _is_dev(dgain) and delay.dtype == torch.int32 and dgain.dtype == torch.float32 and delay.is_contiguous()
+                and dgain.is_contiguous() and delay.dim() == 2 and delay.shape == dgain.shape and delay.device == dev):
+            raise ValueError("delay / dgain must be contiguous int32 / float32 (P, C) tensors on the banks' device")
+        P, C = (int(v) for v in delay.shape)
+        o = outs[i]
+        if not (_is_dev(o) and o.dtype == torch.float32 and tuple(o.shape) == (P, C, int(L)) and o.is_contiguous() and o.device == dev):
+            raise ValueError("outs[i] must be a contiguous float32 device tensor of shape (P, C, L)")
+        prm[i] = _lib.SsRirParams(P, C, int(L), float(fs), float(rt60), float(tail_gain), float(rho), int(seed) & 0xFFFFFFFF,
+                                  ctypes.cast(ctypes.c_void_p(delay.data_ptr()), _lib.c_i32p), ctypes.cast(ctypes.c_void_p(dgain.data_ptr()), _lib.c_f32p))
+    vp = ctypes.c_void_p * n
+    ob = vp(*[ctypes.c_void_p(o.data_ptr()) for o in outs])
+    pk = None
+    if peaks is not None:
+        for p in peaks:
+            if p is not None and not (_is_dev(p) and p.dtype == torch.float32 and p.numel() == 1 and p.device == dev):
+                raise ValueError("a peak must be a one-element float32 tensor on the banks' device")
+        pk = vp(*[ctypes.c_void_p(p.data_ptr()) if p is not None else None for p in peaks])
+    _set_device(outs[0])
+    _lib.check(_lib.load().ss_rir_bank_synth_batch_f32(n, prm, ob, pk, _lib.FLAG_DEVICE_PTR | _lib.FLAG_META_DEVICE, _stream_ptr(outs[0])))
+    return outs
 
 
 @_restores_device

@@ -146,11 +146,9 @@ class SceneRenderer:
             peaks = [torch.empty(1, dtype=torch.float32, device=self.device) for _ in range(3)]
             self._sets[si] = (banks, peaks)
         banks, peaks = self._sets[si]
-        for k, (x, delay, dgain, seg, rt60) in enumerate(spec.speakers):
-            ops.rir_bank_synth(delay, dgain, spec.L, spec.fs, rt60, (seed * 8 + k) & 0x7FFFFFFF, device=self.device, return_peak=True,
-                               out=banks[k], peak_out=peaks[k])
-        for k, (x, delay, dgain, rt60) in enumerate(spec.statics):
-            ops.rir_bank_synth(delay, dgain, spec.L, spec.fs, rt60, (seed * 8 + 4 + k) & 0x7FFFFFFF, device=self.device, out=banks[3 + k])
+        geoms = [(delay, dgain, rt60, (seed * 8 + k) & 0x7FFFFFFF) for k, (x, delay, dgain, seg, rt60) in enumerate(spec.speakers)] + \
+                [(delay, dgain, rt60, (seed * 8 + 4 + k) & 0x7FFFFFFF) for k, (x, delay, dgain, rt60) in enumerate(spec.statics)]
+        ops.rir_bank_synth_batch(geoms, spec.L, spec.fs, banks, list(peaks) + [None, None])      # the five banks of the scene: ONE launch
         return banks, peaks
 
     def prefetch(self, spec: SceneSpec, seed: int):
@@ -172,11 +170,12 @@ class SceneRenderer:
             ev.record(self._k1_stream)
         self._ready = ((id(spec), int(seed)), si, ev)
 
-    def render(self, spec: SceneSpec, seed: int, sirs=(0.0,), snr=15.0, out=None, sync=False, next_scene=None):
+    def render(self, spec: SceneSpec, seed: int, sirs=(0.0,), snr=15.0, out=None, sync=True, next_scene=None):
         """K1 x 3 (bank + tracked peak) -> moving renders with the normalisation deferred; K1 x 2 -> static renders; loudness of
         the five stems in one call; mix of speakers {1, 2} + noise into ``out`` (or a fresh tensor).  Returns (mix, gains).
-        sync=False (default): nothing in a scene waits for the GPU -- the five loudness gains are a float64 device tensor the caller
-        reads when it writes the scene's metadata; sync=True returns them as Python floats (one synchronisation per scene).
+        sync=True (default, the reference's behaviour): the five loudness gains come back as Python floats (one synchronisation per
+        scene).  sync=False: nothing in a scene waits for the GPU -- gains is the float64 device record tensor (5, 4) the caller reads when
+        it writes the scene's metadata (``SonicSim_audio.lufs_gains_from_result``); a scene generator that pipelines scenes wants this.
         next_scene = (spec, seed) of the scene rendered next: its provider runs on the side stream beside this scene's loudness / mix."""
         import torch
         if self.one_launch and spec.L > 4096:

@@ -431,3 +431,40 @@ def test_device_loudness_ebu_tech_3341_cases(gpu):
         got = A.integrated_loudness(torch.from_numpy(x).to(gpu), 48000)
         assert abs(got - want) <= 0.1, (case, got)
         assert abs(got - OL.integrated_loudness(x, 48000)) < 1e-5, case
+
+
+def test_batched_bank_generator_same_values_as_bank_by_bank(gpu):
+    """round 4: the five banks of a scene (three trajectories + two static positions) from ONE launch -- bit for bit the banks and peaks
+    the single-bank entry point produces, interleaved with single launches (the two forms lay their arrival tickets out differently) and
+    for shapes the one-launch form does not cover (different C * L: falls back to bank-by-bank launches)."""
+    from sonicsim_amd import ops, synth
+    scs = [synth.make_scene("tiny", scene=s) for s in range(3)] + [synth.make_scene("tiny", scene=10 + s, P=1) for s in range(2)]
+    L, fs = scs[0].L, scs[0].fs
+    geoms, want, wpk = [], [], []
+    for i, sc in enumerate(scs):
+        d, g = torch.from_numpy(sc.delay).to(gpu), torch.from_numpy(sc.dgain).to(gpu)
+        geoms.append((d, g, sc.rt60, 700 + i))
+        b, pk = ops.rir_bank_synth(d, g, L, fs, sc.rt60, 700 + i, device=gpu, return_peak=True)
+        want.append(b)
+        wpk.append(pk)
+    for rep in range(2):
+        outs = [torch.full_like(b, float("nan")) for b in want]
+        peaks = [torch.zeros(1, device=gpu) for _ in range(3)] + [None, None]
+        ops.rir_bank_synth_batch(geoms, L, fs, outs, peaks)
+        for i in range(5):
+            assert torch.equal(outs[i], want[i]), i
+        assert all(torch.equal(peaks[i], wpk[i]) for i in range(3))
+        b, pk = ops.rir_bank_synth(geoms[1][0], geoms[1][1], L, fs, geoms[1][2], geoms[1][3], device=gpu, return_peak=True)      # a single launch in between
+        assert torch.equal(b, want[1]) and torch.equal(pk, wpk[1])
+    odd = synth.make_scene("tiny", scene=3, L=4001)                              # another C * L: the fallback
+    d, g = torch.from_numpy(odd.delay).to(gpu), torch.from_numpy(odd.dgain).to(gpu)
+    o2 = [torch.empty_like(want[0]), torch.empty((odd.P, odd.C, 4001), device=gpu)]
+    with pytest.raises(ValueError):
+        ops.rir_bank_synth_batch([geoms[0], (d, g, odd.rt60, 5)], L, fs, o2)      # one L per call
+    full = synth.make_scene("cfg2", scene=1)
+    d, g = torch.from_numpy(full.delay).to(gpu), torch.from_numpy(full.dgain).to(gpu)
+    one, pk1 = ops.rir_bank_synth(d, g, full.L, full.fs, full.rt60, 9, device=gpu, return_peak=True)
+    o = [torch.empty_like(one), torch.empty_like(one)]
+    p2 = [torch.zeros(1, device=gpu), torch.zeros(1, device=gpu)]
+    ops.rir_bank_synth_batch([(d, g, full.rt60, 9), (d, g, full.rt60, 9)], full.L, full.fs, o, p2)
+    assert torch.equal(o[0], one) and torch.equal(o[1], one) and torch.equal(p2[0], pk1) and torch.equal(p2[1], pk1)

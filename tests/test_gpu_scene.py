@@ -121,7 +121,7 @@ def test_scene_renderer_prefetched_provider_same_bits(gpu):
             if prefetch and i + 1 < len(order):
                 a = order[i + 1] if announce is None else announce[i]
                 nxt = (specs[a[0]], a[1]) if a is not None else None
-            mix, gains = r.render(specs[si], seed=seed, sirs=(1.5,), snr=12.0, next_scene=nxt)
+            mix, gains = r.render(specs[si], seed=seed, sirs=(1.5,), snr=12.0, next_scene=nxt, sync=False)
             outs.append((mix.clone(), gains.clone()))
         torch.cuda.synchronize()
         return outs
@@ -132,4 +132,6 @@ def test_scene_renderer_prefetched_provider_same_bits(gpu):
             assert torch.equal(m0, m1) and torch.equal(g0, g1)
     assert all(torch.isfinite(m).all() for m, _ in base) and float(base[0][0].abs().max()) > 0
     g = A.lufs_gains_from_result(base[0][1].cpu().numpy())
-    assert len(g) == 5
+    np.random.seed(100)
+    mix_s, gains_s = pipeline.SceneRenderer(specs[0], gpu).render(specs[0], seed=11, sirs=(1.5,), snr=12.0)      # default: synchronous, Python floats
+    assert len(g) == 5 and torch.equal(mix_s, base[0][0]) and np.allclose(gains_s, g, rtol=0, atol=0)

@@ -85,7 +85,7 @@ np.random.seed(2)
 k = [0]
 def scene():
     k[0] += 1
-    rend.render(spec, seed=k[0], sirs=(1.0,), snr=12.0)
+    rend.render(spec, seed=k[0], sirs=(1.0,), snr=12.0, sync=False)
 tsc = timeit(scene, n=10, warm=2)
 out["cfg4_scene_ms"] = tsc * 1e3
 # dataset-side batched mix (row N2): 64 crops of 4 s from resident mono stems

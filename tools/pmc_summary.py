@@ -19,7 +19,7 @@ import os
 import sys
 from collections import defaultdict
 
-KNOWN_BANK_BYTES = 4 * 200 * 8 * 48000      # bench config 2
+KNOWN_BANK_BYTES = int(os.environ.get("PMC_BANK_BYTES", 4 * 200 * 8 * 48000))      # bench config 2 (config 5: 768 000 000)
 
 
 def short(name):
@@ -86,7 +86,7 @@ def main():
             res[k]["write_bytes_raw"] = w_raw
             print(f"  {k}: FETCH raw {f_raw/1e6:.1f} MB -> {f_cor/1e6:.1f} MB   WRITE raw {w_raw/1e6:.1f} MB -> {w_cor/1e6:.1f} MB"
                   f"   total {((f_cor+w_cor)/1e6):.1f} MB per launch")
-    res["_source"] = f"{root}: separate rocprofv3 --pmc passes of `bench.py --steps 3 --warmup 1` (tools/profile.sh), calibrated on k_absmax / k_divide in the same runs"
+    res["_source"] = f"{root}: separate rocprofv3 --pmc passes of `bench.py --no-secondary --steps 3 --warmup 1 {os.environ.get('PMC_BENCH_ARGS', '')}` (tools/profile.sh), calibrated on k_absmax / k_divide in the same runs"
     json.dump(res, open(os.path.join(root, "pmc_summary.json"), "w"), indent=1)
 
 

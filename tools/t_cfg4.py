@@ -29,7 +29,7 @@ def loop(n, gather, stamps=None, sync_every=0):
         out = sg.slot(j) if sg is not None else None
         sir = torch.Tensor(1).uniform_(-6, 6).numpy()
         snr = float(torch.Tensor(1).uniform_(10, 20).numpy()[0])
-        rend.render(pool[j % 4], seed=j, sirs=sir, snr=snr, out=out)
+        rend.render(pool[j % 4], seed=j, sirs=sir, snr=snr, out=out, sync=False)
         if sg is not None:
             sg.submit(j)
         if stamps is not None:
