@@ -28,6 +28,11 @@ ranks itself (torch.distributed.run, one process per GPU) and refuses when the n
   cpu_baseline_all_cores / cpu_smart -- the same algorithm spread over the host cores (oracle/allcores.py; its whole-config output is the
                   parity reference when the single-core leg is a sample), and the segment-wise reformulation (2 instead of P convolutions
                   per sample) on one core.
+  secondary    -- (round 4; N = 1, config 2) the other BASELINE.json configurations and the host-pointer path in the SAME line, each a dict with its
+                  own config.workload, ms_per_step, roofline and cpu_baseline: cfg2_end_to_end_host (NumPy / CPU tensors in, CPU tensor out through
+                  SonicSim_moving.interpolate_moving_audio, with the pinned-DMA time of the same bytes measured beside it -- PCIe inclusive, never
+                  `value`), cfg5, cfg4_per_gpu_share (64 full scenes), cfg1.  --no-secondary / --legs host,cfg5,cfg4,cfg1 select them.
+  roofline.compute -- the arithmetic of the planned transforms over the kernel time against the fp32 vector peak (the bound the kernel lives under).
 The oracle is used here only as the timed CPU baseline and as the checker.
 """
 import argparse
