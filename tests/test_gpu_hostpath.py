@@ -127,3 +127,28 @@ def test_config2_host_path_full_size(gpu):
     print(f"config 2 from pageable host arrays: {best * 1e3:.2f} ms per render ({(st['bytes_up'] + st['bytes_down']) / best / 1e9:.1f} GB/s "
           f"over PCIe, {st['chunks']} chunks, {st['threads']} copy threads)")
     assert np.array_equal(got, want) and st["chunks"] >= 8
+
+
+def test_host_path_edge_shapes_and_errors(gpu, small_chunks):
+    """two positions (never chunked), a bank below the chunking threshold, T not a multiple of anything, one channel; wrong shapes raise
+    before anything is staged; a negative segment length raises like the reference's np.repeat"""
+    from sonicsim_amd import ops
+    for (T, P, C, L) in ((30001, 2, 1, 9001), (8191, 3, 2, 8193), (100000, 17, 1, 20000)):
+        x, bank, _ = golden_inputs(T % 97, T, P, C, L)
+        seg = _segments(np.random.default_rng(T), P, T)
+        want = ops.convolve_moving_seg(torch.from_numpy(x).to(gpu), torch.from_numpy(bank).to(gpu), seg).cpu().numpy()
+        assert np.array_equal(ops.convolve_moving_seg(x, bank, seg), want), (T, P, C, L)
+        assert np.array_equal(ops.convolve_moving_seg(x.astype(np.float64), torch.from_numpy(bank), seg), want)      # float64 / CPU tensors are cast like the reference's data
+    x, bank, _ = golden_inputs(5, 20000, 6, 2, 9000)
+    seg = _segments(np.random.default_rng(1), 6, 20000)
+    with pytest.raises(ValueError):
+        ops.convolve_moving_seg(x, bank, seg[:-1])
+    with pytest.raises(ValueError):
+        ops.convolve_moving_seg(x[:-1], bank, seg)
+    bad = seg.copy()
+    bad[0] -= bad[0] + 5
+    bad[1] += seg[0] + 5
+    with pytest.raises(ValueError):
+        ops.convolve_moving_seg(x, bank, bad)
+    assert np.array_equal(ops.convolve_moving_seg(x, bank, seg),                                                    # the library is still healthy after the errors
+                          ops.convolve_moving_seg(torch.from_numpy(x).to(gpu), torch.from_numpy(bank).to(gpu), seg).cpu().numpy())

@@ -174,3 +174,31 @@ def test_time_sharded_render_on_two_ranks(gpu, config):
     assert tag == "ok" and rel < 2e-6, rel
     assert cuts[0] == 0 and cuts[-1] == shape[1] and 0.3 * shape[1] < cuts[1] < 0.7 * shape[1]
     print(f"{config}: two time shards {cuts} vs one piece: rel RMS {rel:.2e}")
+
+
+@pytest.mark.parametrize("T,P,C,L", [(9000, 2, 1, 4096), (20000, 3, 2, 100), (30000, 5, 1, 4097), (50000, 4, 9, 12288)])
+def test_persistent_engine_edge_shapes(gpu, T, P, C, L):
+    """one partition exactly, a filter shorter than a block, one tap into the second partition, a whole number of partitions; the smallest
+    trajectory (two positions); one channel; empty pushes"""
+    from sonicsim_amd import ops, streaming
+    rng = np.random.default_rng(T)
+    x = torch.from_numpy(rng.standard_normal(T).astype(np.float32)).to(gpu)
+    bank = torch.from_numpy((rng.standard_normal((P, C, L)) * np.exp(-3.0 * np.arange(L) / L)).astype(np.float32)).to(gpu)
+    cuts = np.sort(rng.integers(0, T + 1, size=P - 2)) if P > 2 else np.zeros(0, dtype=np.int64)
+    seg = np.diff(np.concatenate([[0], cuts, [T]])).astype(np.int64)
+    idx, w = moving.expand_segments(seg)
+    ref = moving.convolve_moving_receiver(x.cpu().numpy(), bank.cpu().numpy(), idx, w)
+    sr = streaming.StreamingRenderer(bank, seg)
+    out, pos = [], 0
+    for n in [0, 1, 4095, 0, 4096, 123, T]:
+        n = min(n, T - pos)
+        y = sr.push(x[pos:pos + n])
+        assert y.shape == (C, n)
+        out.append(y)
+        pos += n
+    y = torch.cat(out, dim=1).cpu().numpy()
+    scale = np.sqrt(np.mean(ref.astype(np.float64) ** 2))
+    assert y.shape == ref.shape and np.abs(y - ref).max() < 3e-5 * scale
+    assert sr.info()["pos"] == T
+    sr.close()
+    sr.close()                                                           # idempotent
