@@ -787,6 +787,8 @@ def run_hostpath(args, dev):
 
     from sonicsim_amd import SonicSim_moving as M
     from sonicsim_amd import ops, synth
+    if os.environ.get("BENCH_HOST_BIND"):                  # A/B of the copy-thread placement (tools): 0 scheduler, 1 GPU's node, 2 follow the pages (default)
+        ops.set_host_pipe(bind=int(os.environ["BENCH_HOST_BIND"]))
     sc = synth.make_scene("cfg2", scene=0)
     seg = synth.scene_segments(sc, 0)
     dbank = ops.rir_bank_synth(sc.delay, sc.dgain, sc.L, sc.fs, sc.rt60, sc.bank_seed, device=dev)

@@ -99,9 +99,10 @@ int ss_set_task_queue(int dynamic);
  * that no later chunk touches travels back at once.  Same bits as the device-pointer render.  Buffers the caller pinned itself
  * (ss_host_alloc, hipHostMalloc, hipHostRegister) are recognised and moved by DMA directly, without the staging copy.
  * ss_set_host_pipe: copy threads (0 = keep; default 4: more only contend for the memory system, profiles/r04a), bytes per staging slot (default 16 MiB, 6 up + 4 down),
- * bytes per bank chunk (default 24 MiB, at most 16 chunks), bind (-1 = keep, 0 = default: the copy threads are left to the scheduler, 1 = bound to
- * the CPUs next to the GPU -- sysfs local_cpulist of its PCI function; measured SLOWER when the caller's arrays live on the other socket,
- * profiles/r04d) -- current device.
+ * bytes per bank chunk (default 24 MiB, at most 16 chunks), bind (-1 = keep; 2 = default: the copy threads follow the caller's pages -- bound to the
+ * NUMA node the array being staged lives on (move_pages query), so the staging copy reads locally; 0 = left to the scheduler (measured bimodal:
+ * 6.45 or 8.5 ms per config-2 render from run to run); 1 = bound to the CPUs next to the GPU (sysfs local_cpulist; slower when the caller's arrays
+ * live on the other socket: 8.4 ms, profiles/r04d)) -- current device.
  * ss_host_path_stats: {seconds inside the last host-pointer render call, bytes up, bytes down, bank chunks, direct (pinned) transfers,
  * copy threads} of the current device. */
 int ss_set_host_pipe(int threads, int64_t slot_bytes, int64_t chunk_bytes, int bind);

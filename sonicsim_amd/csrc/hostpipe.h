@@ -36,22 +36,30 @@ struct CopyPool {
         th.clear();
         stop = false;
     }
-    std::vector<int> cpus;      // workers are bound to these CPUs (the NUMA node the GPU and the pinned slots hang off); empty = unbound
+    std::vector<int> cpus;      // workers are bound to these CPUs; empty = unbound (then the caller's thread takes a slice itself)
+    int bound_node = -2;        // NUMA node the workers currently follow (-2: never bound, -1: unbound)
+    bool cpus_all_workers = false;   // the caller's thread only waits (it may sit on the far socket) even while no CPU list is set
+    void apply_affinity() {
+        cpu_set_t set;
+        CPU_ZERO(&set);
+        if (cpus.empty()) {
+            for (int c = 0; c < CPU_SETSIZE; ++c) CPU_SET(c, &set);
+        } else {
+            for (int c : cpus) if (c >= 0 && c < CPU_SETSIZE) CPU_SET(c, &set);
+        }
+        for (auto& t : th) pthread_setaffinity_np(t.native_handle(), sizeof(set), &set);      // best effort
+    }
     void resize(int n) {      // n = threads in all, the caller's included
         if (n < 1) n = 1;
         // bound workers: the caller's thread may sit on the far socket, so it only waits; unbound: it takes a slice itself
-        const int workers = cpus.empty() ? n - 1 : n;
+        const bool all_workers = !cpus.empty() || cpus_all_workers;
+        const int workers = all_workers ? n : n - 1;
         if ((int)th.size() == workers) return;
         shutdown();
         const int g0 = gen;     // a new worker must not mistake jobs that ran before it existed for a pending one
-        const int first = cpus.empty() ? 1 : 0;
+        const int first = all_workers ? 0 : 1;
         for (int i = 0; i < workers; ++i) th.emplace_back([this, i, g0, first] { run(i + first, g0); });
-        if (!cpus.empty()) {
-            cpu_set_t set;
-            CPU_ZERO(&set);
-            for (int c : cpus) if (c >= 0 && c < CPU_SETSIZE) CPU_SET(c, &set);
-            for (auto& t : th) pthread_setaffinity_np(t.native_handle(), sizeof(set), &set);      // best effort
-        }
+        if (!cpus.empty()) apply_affinity();
     }
     // slice i of the concatenation of all pieces
     void slice(int i) {
@@ -84,7 +92,7 @@ struct CopyPool {
     void go() {
         total = 0;
         for (const Seg& sg : segs) total += sg.n;
-        const bool caller_copies = cpus.empty();
+        const bool caller_copies = cpus.empty() && !cpus_all_workers;      // (matches resize(): all-worker layouts leave the caller waiting)
         parts = (int)th.size() + (caller_copies ? 1 : 0);
         if (total < ((size_t)256 << 10) || th.empty()) {      // small jobs: the wake-up costs more than it saves
             parts = 1;
@@ -112,8 +120,11 @@ struct HostPipe {
     size_t slot_bytes = (size_t)16 << 20;
     size_t chunk_bytes = (size_t)24 << 20;   // render() cuts a host bank into chunks of about this size (whole trajectory positions)
     int threads = 0;                    // 0 = choose at first use
-    bool bind = false;                  // copy threads bound to the CPUs next to the GPU (ss_set_host_pipe): OFF by default -- the caller's array usually lives
-                                        // next to the caller's thread, and workers on the GPU's socket then READ across the sockets: 8.4 against 6.45 ms (profiles/r04d)
+    int bind = 2;                       // copy threads: 0 = left to the scheduler, 1 = bound to the CPUs next to the GPU, 2 (default) = they FOLLOW THE CALLER'S
+                                        // PAGES -- bound to the NUMA node the array being staged lives on (move_pages query), so the memcpy READS locally and
+                                        // posts its writes to the slots across the socket link.  Left alone the threads drift: the same call measured 6.45 or
+                                        // 8.5 ms from one run to the next; bound to the GPU's node they read remotely: 8.4 ms (profiles/r04d, r04p)
+    int threads_target = 0;             // (bind == 2) the pool is built with all-worker layout
     hipStream_t up = nullptr, down = nullptr;
     char* ups[NUP] = {};
     hipEvent_t upev[NUP] = {};
@@ -153,7 +164,8 @@ static int hp_ensure(HostPipe& h) {
     }
     // optional: the CPUs next to this GPU (sysfs local_cpulist of its PCI function), where the pinned slots live
     h.pool.cpus.clear();
-    if (h.bind) {
+    h.pool.bound_node = -2;
+    if (h.bind == 1) {
         int dev = 0;
         char bus[64] = {0};
         if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetPCIBusId(bus, sizeof(bus), dev) == hipSuccess) {
@@ -180,8 +192,51 @@ static int hp_ensure(HostPipe& h) {
         const unsigned hw = std::thread::hardware_concurrency();
         h.threads = hw >= 8 ? 4 : (hw >= 2 ? 2 : 1);      // measured (profiles/r04a): 4 memcpy threads feed a Gen5 x16 link, more only contend
     }
+    h.pool.cpus_all_workers = h.bind == 2;           // the real CPU list follows the first staged array (hp_follow)
     h.pool.resize(h.threads);
+    if (h.bind == 2) h.pool.bound_node = -1;
     return SS_OK;
+}
+
+// NUMA node of the page that holds `p` (-1: unknown / not faulted in yet)
+static int hp_page_node(const void* p) {
+#if defined(__linux__) && defined(SYS_move_pages)
+    void* page = (void*)((uintptr_t)p & ~(uintptr_t)4095);
+    int status = -1;
+    if (syscall(SYS_move_pages, 0, 1UL, &page, (const int*)nullptr, &status, 0) == 0 && status >= 0) return status;
+#endif
+    return -1;
+}
+
+static bool hp_node_cpus(int node, std::vector<int>& out) {
+    char path[96];
+    snprintf(path, sizeof(path), "/sys/devices/system/node/node%d/cpulist", node);
+    FILE* f = fopen(path, "r");
+    if (!f) return false;
+    char line[4096] = {0};
+    out.clear();
+    if (fgets(line, sizeof(line), f))
+        for (char* tok = strtok(line, ",\n"); tok; tok = strtok(nullptr, ",\n")) {
+            int a = 0, b = 0;
+            const int k = sscanf(tok, "%d-%d", &a, &b);
+            if (k == 1) b = a;
+            if (k >= 1) for (int c = a; c <= b && out.size() < 4096; ++c) out.push_back(c);
+        }
+    fclose(f);
+    return !out.empty();
+}
+
+// bind == 2: the workers follow the pages of the array that is about to be staged
+static void hp_follow(HostPipe& h, const void* p, size_t bytes) {
+    if (h.bind != 2 || h.pool.th.empty()) return;
+    int node = hp_page_node(p);
+    if (node < 0 && bytes > 4096) node = hp_page_node((const char*)p + bytes / 2);
+    if (node < 0 || node == h.pool.bound_node) return;
+    std::vector<int> cpus;
+    if (!hp_node_cpus(node, cpus)) return;
+    h.pool.cpus.swap(cpus);
+    h.pool.apply_affinity();
+    h.pool.bound_node = node;
 }
 
 static void hp_destroy(HostPipe& h) {
@@ -252,6 +307,7 @@ template <class F> static int hp_upload(HostPipe& h, void* dst, const void* src,
     h.st_bytes_up += (double)bytes;
     const bool direct = hp_is_pinned(src);
     if (direct) ++h.st_direct;
+    else hp_follow(h, src, bytes);
     for (size_t off = 0; off < bytes; off += h.slot_bytes) {
         const size_t n = bytes - off < h.slot_bytes ? bytes - off : h.slot_bytes;
         if (direct) {

@@ -6,6 +6,8 @@
 
 #include <pthread.h>
 #include <sched.h>
+#include <sys/syscall.h>
+#include <unistd.h>
 
 #include <cctype>
 #include <chrono>
@@ -1918,6 +1920,11 @@ int render(int mode, const float* x, int64_t T, const float* bank, int32_t P, in
         nchunk = (int)std::min<size_t>(16, bank_bytes / hp.chunk_bytes);
         if (nchunk > P / 2) nchunk = P / 2;
         if (nchunk < 2) nchunk = 1;
+    } else if (!dev && bank_dev && g14 && fast_plan && sizeof(float) * (size_t)C * T >= ((size_t)8 << 20)) {
+        // a RESIDENT bank rendered for host x / y: nothing to upload, but the 4CT bytes of y take ~3x as long over PCIe as the render itself --
+        // four launches in trajectory order let the first quarter of y travel while the other three are rendered (1.13 -> ~0.8 ms at config 2)
+        nchunk = P / 2 < 4 ? P / 2 : 4;
+        if (nchunk < 2) nchunk = 1;
     }
     const bool chunked = nchunk > 1;
     if (chunked && (rc = load_mod13(c, false))) return rc;
@@ -2055,10 +2062,12 @@ int render(int mode, const float* x, int64_t T, const float* bank, int32_t P, in
                 const int r0 = (int)((int64_t)P * k / nchunk), r1 = (int)((int64_t)P * (k + 1) / nchunk);
                 if (pos_bytes * (size_t)r1 > up_bytes) break;
                 (void)r0;
-                hipEvent_t e_up;
-                if ((rc2 = hp_event(hp, &e_up))) return rc2;
-                HIPCHK(hipEventRecord(e_up, hp.up));
-                HIPCHK(hipStreamWaitEvent(stream, e_up, 0));
+                if (!bank_dev) {
+                    hipEvent_t e_up;
+                    if ((rc2 = hp_event(hp, &e_up))) return rc2;
+                    HIPCHK(hipEventRecord(e_up, hp.up));
+                    HIPCHK(hipStreamWaitEvent(stream, e_up, 0));
+                }
                 const int32_t nt = chunk_off[(size_t)k + 1] - chunk_off[(size_t)k];
                 if (nt > 0) {
                     ProfScope ps(c, stream, 0);
@@ -2092,7 +2101,9 @@ int render(int mode, const float* x, int64_t T, const float* bank, int32_t P, in
             }
             return SS_OK;
         };
-        if ((rc = hp_upload(hp, c->ws[WS_BANK], bank, bank_bytes, launch_ready))) return rc;
+        if (bank_dev) {
+            if ((rc = launch_ready((size_t)-1))) return rc;          // every chunk is "uploaded": launched back to back, y slices follow each
+        } else if ((rc = hp_upload(hp, c->ws[WS_BANK], bank, bank_bytes, launch_ready))) return rc;
         mark(4); mark(5);
         if ((rc = hp_finish(hp))) return rc;
         mark(6);
@@ -2511,8 +2522,8 @@ int ss_set_host_pipe(int threads, int64_t slot_bytes, int64_t chunk_bytes, int b
     HostPipe& h = c->pipe;
     if (threads > 256 || (slot_bytes > 0 && (slot_bytes < (1 << 16) || slot_bytes > ((int64_t)1 << 30))) || (chunk_bytes > 0 && chunk_bytes < (1 << 20)))
         return fail(SS_EINVAL, "ss_set_host_pipe: threads <= 256, 64 KiB <= slot_bytes <= 1 GiB, chunk_bytes >= 1 MiB (0 / negative = keep)");
-    const bool rebind = bind >= 0 && (bind != 0) != h.bind;
-    if (rebind) h.bind = bind != 0;
+    const bool rebind = bind >= 0 && bind <= 2 && bind != h.bind;
+    if (rebind) h.bind = bind;
     if ((slot_bytes > 0 && (size_t)slot_bytes != h.slot_bytes) || rebind) {
         if (h.up) {
             HIPCHK(hipStreamSynchronize(h.up));

@@ -124,6 +124,19 @@ def test_config2_host_path_full_size(gpu):
         got = ops.convolve_moving_seg(sc.x, bank, seg)
         best = min(best, time.perf_counter() - t0)
     st = ops.host_path_stats()
+    assert st["direct_transfers"] >= 1                                          # the result came back into a leased pinned buffer by DMA
+    ops.set_pinned_outputs(False)
+    try:
+        plain = ops.convolve_moving_seg(sc.x, bank, seg)
+        assert ops.host_path_stats()["direct_transfers"] == 0 and np.array_equal(plain, want)
+    finally:
+        ops.set_pinned_outputs(True)
+    keep = [ops.convolve_moving_seg(sc.x, dbank, seg, host_io=True) for _ in range(10)]      # more live results than the pool leases: pageable again, same bits
+    assert all(np.array_equal(k, want) for k in keep)
+    del keep
+    got_xy = ops.convolve_moving_seg(sc.x, dbank, seg, host_io=True)           # resident bank: four launches in trajectory order, y travels behind each
+    st_xy = ops.host_path_stats()
+    assert np.array_equal(got_xy, want) and st_xy["chunks"] == 4 and st_xy["bytes_up"] == 4 * sc.T, st_xy
     print(f"config 2 from pageable host arrays: {best * 1e3:.2f} ms per render ({(st['bytes_up'] + st['bytes_down']) / best / 1e9:.1f} GB/s "
           f"over PCIe, {st['chunks']} chunks, {st['threads']} copy threads)")
     assert np.array_equal(got, want) and st["chunks"] >= 8
