@@ -636,6 +636,39 @@ def run_scenes(args, rank, local_rank, world, dev):
                       "frac_with_k1_writes": (scene_bytes + k1_bytes) / (ms_scene * 1e-3) / 1e9 / HBM_PEAK_GBS,
                       "note": "whole-scene figure: every kernel of the scene (K1 x 5, spectra, render, loudness x 4 launches, mix) and the gaps between them "
                               "against the bytes of the 8d model; K1's 0.92 GB of bank writes are work of config 4's timed region that the model does not count"}}
+    # ---- per-stage breakdown (stages one after the other on one stream, no prefetch, torch events between them; 8 scenes after the timed region)
+    stages = None
+    try:
+        from sonicsim_amd import mixing
+        acc = {"k1_five_banks_one_launch": 0.0, "spectra_plus_render_one_launch": 0.0, "loudness_five_stems": 0.0, "mix": 0.0}
+        nst = 8
+        for rep in range(nst + 2):
+            sp_ = pool[rep % len(pool)]
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+            np.random.seed(123 + rep)
+            ev[0].record()
+            banks, peaks = rend._provide(sp_, 40_000 + rep, 0)
+            ev[1].record()
+            xs_ = [q[0] for q in sp_.speakers] + [q[0] for q in sp_.statics]
+            ops.convolve_scene(xs_, banks, [q[3] for q in sp_.speakers] + [None, None], peaks=list(peaks) + [None, None], outs=[rend.stack[i] for i in range(5)])
+            ev[2].record()
+            nstack, _res = A.get_lufs_norm_audio_batch(rend.stack, sp_.fs, pipeline.LUFS_TARGETS, allow_many_channels=True, sync=False)
+            ev[3].record()
+            mixing.mix_sources(nstack[:2], nstack[3][None], np.asarray([1.5], np.float32), 15.0, keep_speakers=True)
+            ev[4].record()
+            torch.cuda.synchronize()
+            if rep >= 2:
+                for k_, (a_, b_) in zip(acc, zip(ev[:-1], ev[1:])):
+                    acc[k_] += a_.elapsed_time(b_)
+        sb = {"k1_five_banks_one_launch": k1_bytes, "spectra_plus_render_one_launch": launch_bytes + 5 * stem, "loudness_five_stems": 5 * 2 * stem, "mix": 4 * stem}
+        stages = {k_: {"ms": v_ / nst, "algorithmic_bytes": sb[k_], "achieved_GBs": sb[k_] / (v_ / nst * 1e-3) / 1e9, "frac": sb[k_] / (v_ / nst * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                  for k_, v_ in acc.items()}
+        stages["note"] = ("stages launched one after the other on one stream with torch events between them (no provider prefetch), mean of 8 scenes; bytes: K1 = the "
+                          "banks it writes, render = SURVEY 8d's render bytes + the zero fill of the five stems, loudness = read + write of five stems, mix = read 3 + "
+                          "write 1; the sum exceeds ms_per_step because the timed region overlaps the next scene's K1 with loudness / mix")
+    except Exception as e:                                   # noqa: BLE001 -- informational
+        stages = {"error": repr(e)}
+    roof["scene"]["stages"] = stages
     cpu = None
     if world == 1 and getattr(args, "cpu_seconds", 0) > 0:
         cpu = cpu_scene_chain(spec, rend, dev, getattr(args, "cfg2_cpu_seconds", None), audio_s)
