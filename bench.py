@@ -195,12 +195,12 @@ def render_flops(seg, P, C, L, block=4096, jmax=4):
             continue
         j = a0 // block
         nb = -(-(a2 - j * block) // block)
-        while nb > 0:
-            nj = min(jmax, nb)
+        ntask = -(-nb // jmax)
+        for k in range(ntask):                      # plan.h row_tasks: the fewest tasks; of (nearly) equal size from jmax + 2 blocks on, else greedy
+            nj = (nb // ntask + (1 if k < nb % ntask else 0)) if nb >= jmax + 2 else min(jmax, nb - k * jmax)
             np_eff = min(NP, j + nj)
             total += np_eff * fft + np_eff * nj * mac + nj * fft
             j += nj
-            nb -= nj
     return total * C
 
 

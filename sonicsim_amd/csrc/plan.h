@@ -179,22 +179,36 @@ inline void merge_lpt_xcd(Plan& plan, int NP, int groups, std::vector<Task>& out
 // rs > 0 (assembly engine): the input spectra exist on a grid of block >> rs samples, so a row's first block may start at any
 // multiple of that hop instead of a multiple of `block` -- a row of 2.3 blocks then never spills into a fourth block and fewer
 // rows need a second task.  Task::j0 is in HOP units (first sample = j0 * (block >> rs)); blocks of a task stay `block` apart.
+inline int g_plan_balanced = 1;
 template <class F> inline void row_tasks(int64_t a0, int64_t a2, int block, int jmax, int rs, F f) {
     if (a2 <= a0) return;
     const int64_t hop = block >> rs;
     int64_t jh = a0 / hop;
     int64_t nb = (a2 - jh * hop + block - 1) / block;
-    while (nb > 0) {
-        const int nj = (int)std::min<int64_t>(jmax, nb);
+    // a row of jmax + 2 or more blocks is cut into the FEWEST tasks, of (nearly) EQUAL size (round 4; rounds 1-3 cut greedily: 4 + 2 instead of
+    // 3 + 3): tasks of one row then run at the same pace, so the two that read the same taps stay within the L2's reach of each other
+    // (plan_seg_lpt puts them next to each other in the queue), and the largest task is smaller.  Same (row, block) pairs, same bits.
+    if (!g_plan_balanced || nb < jmax + 2) {      // jmax + 1 blocks stay jmax + 1 (config 2's rare long rows: measured better, profiles/r04u);
+                                                   // SS_PLAN_SPLIT=0 (tuning build): the greedy cut of rounds 1-3 throughout
+        while (nb > 0) {
+            const int nj = (int)std::min<int64_t>(jmax, nb);
+            f((int)jh, nj);
+            jh += (int64_t)nj << rs;
+            nb -= nj;
+        }
+        return;
+    }
+    const int64_t ntask = (nb + jmax - 1) / jmax;
+    for (int64_t k = 0; k < ntask; ++k) {
+        const int nj = (int)(nb / ntask + (k < nb % ntask ? 1 : 0));
         f((int)jh, nj);
         jh += (int64_t)nj << rs;
-        nb -= nj;
     }
 }
 
 inline void plan_seg_lpt(const std::vector<int64_t>& seg_start /*[P], last == T*/, int P, int C, int block, int jmax, int NP,
                          std::vector<Task>& out, std::vector<int32_t>& scratch, int groups = 1, int nwg = 0, int rs = 0, int tail_pct = 0,
-                         int32_t* main_out = nullptr) {
+                         int32_t* main_out = nullptr, bool pair_rows = true) {
     out.clear();
     constexpr int MAXCOST = 4096;
     auto cost = [NP, rs](int j0, int nj) {
@@ -223,12 +237,23 @@ inline void plan_seg_lpt(const std::vector<int64_t>& seg_start /*[P], last == T*
         scratch.assign((size_t)groups * MAXCOST + groups + 1, 0);
         int32_t* hist = scratch.data();                       // [groups][MAXCOST]
         int32_t* gcount = scratch.data() + (size_t)groups * MAXCOST;
+        // Sort key of a task = the cost of its row's MOST EXPENSIVE task (round 4): a row that spans more than jmax blocks is cut into
+        // several tasks (config 5: every row, 4 + 2..3 blocks) and each of them streams the whole row from HBM.  Keyed by their own costs the
+        // tasks of a row sit far apart in the queue and the row is read twice (PMC: 1.73 GB fetched for a 0.77 GB bank, profiles/r04j/cfg5);
+        // keyed by the row they are NEIGHBOURS in their XCD's queue, are taken by workgroups of that XCD at the same moment, and the second
+        // reader of every 16 KB partition finds it in the XCD's L2.  (Rows of one task -- config 2, mostly -- keep their order.)
+        auto rowkey = [&](int64_t a0, int64_t a2) {
+            int k = 0;
+            row_tasks(a0, a2, block, jmax, rs, [&](int j, int nj) { const int c = cost(j, nj); if (c > k) k = c; });
+            return k;
+        };
         for (int r = 0; r < P; ++r) {
             const int64_t a0 = seg_start[r > 0 ? r - 1 : r], a2 = seg_start[r < P - 1 ? r + 1 : r];
             if (a2 <= a0) continue;
             const int g = group_of(r);
+            const int key = pair_rows ? rowkey(a0, a2) : -1;
             row_tasks(a0, a2, block, jmax, rs, [&](int j, int nj) {
-                hist[(size_t)g * MAXCOST + cost(j, nj)] += C;
+                hist[(size_t)g * MAXCOST + (pair_rows ? key : cost(j, nj))] += C;
                 gcount[g] += C;
             });
         }
@@ -240,6 +265,22 @@ inline void plan_seg_lpt(const std::vector<int64_t>& seg_start /*[P], last == T*
             const int64_t a0 = seg_start[r > 0 ? r - 1 : r], a2 = seg_start[r < P - 1 ? r + 1 : r];
             if (a2 <= a0) continue;
             const int g = group_of(r);
+            const int key = pair_rows ? rowkey(a0, a2) : -1;
+            if (pair_rows) {
+                // channel-major inside a row: (task A, c), (task B, c), (task A, c + 1), ... -- the two readers of filter (r, c) take
+                // CONSECUTIVE tickets, i.e. start ~one task-start interval apart, well inside the time a tap line survives in the XCD's L2
+                int32_t tj[16], tn[16];
+                int nt = 0;
+                row_tasks(a0, a2, block, jmax, rs, [&](int j, int nj) { if (nt < 16) { tj[nt] = (int32_t)j; tn[nt] = nj; ++nt; } });
+                int32_t& at = hist[(size_t)g * MAXCOST + key];
+                for (int c = 0; c < C; ++c)
+                    for (int k = 0; k < nt; ++k) {
+                        Task t;
+                        t.row = r; t.chan = c; t.j0 = tj[k]; t.nj = tn[k];
+                        tmp[(size_t)at++] = t;
+                    }
+                continue;
+            }
             row_tasks(a0, a2, block, jmax, rs, [&](int j, int nj) {
                 int32_t& at = hist[(size_t)g * MAXCOST + cost(j, nj)];
                 for (int c = 0; c < C; ++c) {
@@ -370,11 +411,17 @@ inline void plan_scene_lpt(const SceneSrc* src, int nsrc, int64_t T, int C, int 
             acc += rc;
             i = e;
         }
-        // descending cost inside this source's share of every queue (stable: time order inside a cost class)
+        // descending cost inside this source's share of every queue (stable: time order inside a cost class); the key of a task is the cost
+        // of its row's most expensive task, so that the tasks of one row stay neighbours and share the row's taps in their XCD's L2 (plan_seg_lpt)
+        static thread_local std::vector<int32_t> rowmax;
+        rowmax.assign((size_t)(src[s].P > 1 ? src[s].P : 1), 0);
+        if (src[s].P > 1)
+            for (const RT& e : rt) rowmax[(size_t)e.row] = std::max(rowmax[(size_t)e.row], e.c);
+        auto key = [&](const Task& t) { return src[s].P > 1 ? (int)rowmax[(size_t)t.row] : cost(t.j0, t.nj); };
         for (int g = 0; g < groups; ++g) {
             auto& v = q[(size_t)g];
             auto first = std::find_if(v.begin(), v.end(), [s](const Task& t) { return (t.chan >> 16) == s; });
-            std::stable_sort(first, v.end(), [&](const Task& a, const Task& b) { return cost(a.j0, a.nj) > cost(b.j0, b.nj); });
+            std::stable_sort(first, v.end(), [&](const Task& a, const Task& b) { return key(a) > key(b); });
         }
     }
     size_t total_n = 0, m = (size_t)-1;

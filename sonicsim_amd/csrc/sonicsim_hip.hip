@@ -1935,9 +1935,12 @@ int render(int mode, const float* x, int64_t T, const float* bank, int32_t P, in
         static const int plan_groups = knob("SS_PLAN_GROUPS") ? atoi(knob("SS_PLAN_GROUPS")) : 8;
         static const int plan_snake = knob("SS_PLAN_SNAKE") ? atoi(knob("SS_PLAN_SNAKE")) : 1;
         static const int plan_tail = knob("SS_PLAN_TAIL") ? atoi(knob("SS_PLAN_TAIL")) : 12;      // % of a range's tasks that go to the shared tail queue
+        static const int plan_split = knob("SS_PLAN_SPLIT") ? (g_plan_balanced = atoi(knob("SS_PLAN_SPLIT")) != 0) : 1;
+        (void)plan_split;
+        static const int plan_pair = knob("SS_PLAN_PAIR") ? atoi(knob("SS_PLAN_PAIR")) : 1;       // tasks of one row adjacent in the queue (plan.h; tuning build: 0 = by their own cost)
         const bool two_level = g14 && c->dynq && plan_groups == 8 && !chunked;
         plan_seg_lpt(c->seg_start, P, C, BB, JM, NPart, c->plan.tasks[0], c->plan_scratch, (g14 && plan_groups > 1 && plan_groups <= 64) ? plan_groups : 1,
-                     (plan_snake && !two_level) ? c->num_cu : 0, rs, two_level ? plan_tail : 0, &qmain);
+                     (plan_snake && !two_level) ? c->num_cu : 0, rs, two_level ? plan_tail : 0, &qmain, plan_pair != 0);
         c->plan.tasks[1].clear();
         if (chunked) {      // stable counting sort of the list by the chunk of the task's row (the LPT / XCD order survives inside a chunk)
             std::vector<Task>& tk = c->plan.tasks[0];
