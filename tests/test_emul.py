@@ -187,6 +187,39 @@ def test_segment_planner_options_cover_every_sample_once(emul):
                 assert m.value == n
 
 
+def test_planner_keeps_the_tasks_of_a_row_together(emul):
+    """round 4 (plan.h::plan_seg_lpt): a row that spans more than four blocks is rendered by several tasks, each streaming the row's taps from
+    HBM.  Keyed by the row's most expensive task and emitted channel-major, the tasks of (row, channel) take CONSECUTIVE tickets of their XCD's
+    queue -- so the second reader finds the taps in that XCD's L2 (config 5: FETCH 1.75 -> 1.25 GB per render) -- and rows of six or more blocks
+    are cut into tasks of equal size."""
+    i32 = ctypes.POINTER(ctypes.c_int32)
+    G = 8
+    seg = np.full(63, 11520, dtype=np.int64)                       # config 5's proportions: every row spans 2 x 11 520 samples = 6-7 blocks
+    Pn, C, L = 64, 4, 96000
+    out = np.zeros((4000, 4), np.int32)
+    m = ctypes.c_int32(0)
+    n = emul.emul_plan_dump_ex(P(seg, ip), Pn, C, L, G, 0, 0, 0, ctypes.byref(m), P(out, i32), len(out))
+    t = out[:n]
+    assert n > 0 and m.value == n
+    per_row = {}
+    for row, chan, j0, nj in t:
+        per_row.setdefault((int(row), int(chan)), []).append(int(nj))
+    two = {k: v for k, v in per_row.items() if len(v) >= 2}
+    assert len(two) > 0.8 * len(per_row)                           # (the first and last rows are shorter)
+    assert all(max(v) - min(v) <= 1 for v in per_row.values())     # equal cut: 3 + 3 or 4 + 3, never 4 + 2
+    # the list is the eight queues interleaved (position i -> queue i % 8 while every queue has tasks): inside a queue, consecutive tickets
+    counts = [int(((np.arange(n) % G) == g).sum()) for g in range(G)]
+    full = min(counts) * G
+    for g in range(G):
+        q = [tuple(int(v) for v in t[i][:2]) for i in range(g, full, G)]
+        where = {}
+        for i, key in enumerate(q):
+            where.setdefault(key, []).append(i)
+        for key, idx in where.items():
+            if len(idx) >= 2:
+                assert idx == list(range(idx[0], idx[0] + len(idx))), (g, key, idx)
+
+
 def test_scene_planner_tiles_every_source(emul):
     """plan.h::plan_scene_lpt (ss_convolve_scene_f32: all renders of a scene in one launch): per source exactly the tasks the single-source
     planner would emit -- a moving source's rows tile the blocks that hold their samples, a static source covers every block once per
