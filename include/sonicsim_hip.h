@@ -220,7 +220,11 @@ int ss_rms_db_f32(const float* x, int64_t n, int32_t count, double* out_db, uint
  * sirs[S-1] (host), snr (dB).  mix[n] = sum_s speakers[s] + g_n * sum_k noises[k] with
  *   g_i = 10^(min(E(spk0) - E(spk_i) - sir_i, 40)/20),  g_n = 10^(min(E(speech) - E(noise) - snr, 40)/20).
  * gains_out (host, may be NULL) receives [g_1..g_{S-1}, g_n].  No host synchronisation unless
- * gains_out != NULL or host-pointer mode. */
+ * gains_out != NULL or host-pointer mode.
+ * Reproducibility: the energies behind the gains are float64 sums whose ORDER depends on whether the 16-byte-vector kernels apply (n % 4 == 0
+ * and 16-byte aligned pointers) or the scalar ones; the same stems give bit-identical gains run to run and for every buffer of the same
+ * alignment class, but a crop that starts at an odd offset (scalar form) may differ from the aligned form in the last bits of a gain (1e-16
+ * relative in the energies).  The goldens of movingdatamodule.py pin the aligned form. */
 int ss_mix_f32(float* speakers, int32_t S, const float* noises, int32_t N, int64_t n, const float* sirs,
                float snr, float* mix, float* gains_out, uint32_t flags, void* stream);
 
