@@ -130,6 +130,7 @@ struct HostPipe {
     hipEvent_t upev[NUP] = {};
     bool upbusy[NUP] = {};
     int upnext = 0;
+    size_t ramp = (size_t)2 << 20;      // size of the next upload piece (reset at the start of every host-pointer call)
     char* dns[NDOWN] = {};
     hipEvent_t dnev[NDOWN] = {};
     int dnnext = 0;
@@ -308,8 +309,11 @@ template <class F> static int hp_upload(HostPipe& h, void* dst, const void* src,
     const bool direct = hp_is_pinned(src);
     if (direct) ++h.st_direct;
     else hp_follow(h, src, bytes);
-    for (size_t off = 0; off < bytes; off += h.slot_bytes) {
-        const size_t n = bytes - off < h.slot_bytes ? bytes - off : h.slot_bytes;
+    for (size_t off = 0; off < bytes;) {
+        // pieces ramp up from 2 MiB to one slot: the DMA engine starts behind a 2 MiB copy instead of waiting for the first 16 MiB to be staged
+        size_t piece = h.ramp < h.slot_bytes ? h.ramp : h.slot_bytes;
+        if (h.ramp < h.slot_bytes) h.ramp *= 2;
+        const size_t n = bytes - off < piece ? bytes - off : piece;
         if (direct) {
             HIPCHK(hipMemcpyAsync((char*)dst + off, (const char*)src + off, n, hipMemcpyHostToDevice, h.up));
         } else {
@@ -327,6 +331,7 @@ template <class F> static int hp_upload(HostPipe& h, void* dst, const void* src,
         int rc = progress(off + n);
         if (rc) return rc;
         if ((rc = hp_drain(h, false))) return rc;
+        off += n;
     }
     return SS_OK;
 }

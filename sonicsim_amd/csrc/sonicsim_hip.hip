@@ -1789,6 +1789,7 @@ int render(int mode, const float* x, int64_t T, const float* bank, int32_t P, in
         for (double& m : hp.st_mark) m = 0;
         hp.pending.clear();
         hp.evused = 0;
+        hp.ramp = (size_t)2 << 20;
         hp.st_bytes_up = hp.st_bytes_down = hp.st_seconds = 0;
         hp.st_chunks = hp.st_direct = 0;
         if ((rc = ws_ensure(c, WS_X, sizeof(float) * T))) return rc;
