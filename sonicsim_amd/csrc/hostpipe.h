@@ -124,7 +124,7 @@ struct HostPipe {
                                         // PAGES -- bound to the NUMA node the array being staged lives on (move_pages query), so the memcpy READS locally and
                                         // posts its writes to the slots across the socket link.  Left alone the threads drift: the same call measured 6.45 or
                                         // 8.5 ms from one run to the next; bound to the GPU's node they read remotely: 8.4 ms (profiles/r04d, r04p)
-    int threads_target = 0;             // (bind == 2) the pool is built with all-worker layout
+    bool dirty = false;                 // a host-pointer call is under way (or ended in an error before hp_finish): the next call drains both streams first
     hipStream_t up = nullptr, down = nullptr;
     char* ups[NUP] = {};
     hipEvent_t upev[NUP] = {};
@@ -385,5 +385,23 @@ static int hp_finish(HostPipe& h) {
     HIPCHK(hipStreamSynchronize(h.up));
     for (bool& b : h.upbusy) b = false;
     h.evused = 0;
+    h.dirty = false;
+    return SS_OK;
+}
+
+// start of a host-pointer call: per-call state, and -- if the previous call ended in an error half way -- nothing of it still in flight
+static int hp_begin(HostPipe& h) {
+    if (h.dirty) {
+        HIPCHK(hipStreamSynchronize(h.down));
+        HIPCHK(hipStreamSynchronize(h.up));
+        for (bool& b : h.upbusy) b = false;
+    }
+    h.dirty = true;
+    h.pending.clear();
+    h.evused = 0;
+    h.ramp = (size_t)2 << 20;
+    h.st_bytes_up = h.st_bytes_down = h.st_seconds = 0;
+    h.st_chunks = h.st_direct = 0;
+    for (double& m : h.st_mark) m = 0;
     return SS_OK;
 }

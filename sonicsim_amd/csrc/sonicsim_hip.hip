@@ -1786,12 +1786,7 @@ int render(int mode, const float* x, int64_t T, const float* bank, int32_t P, in
     auto mark = [&](int i) { if (!dev) hp.st_mark[i] = std::chrono::duration<double>(std::chrono::steady_clock::now() - host_t0).count(); };
     if (!dev) {
         if ((rc = hp_ensure(hp))) return rc;
-        for (double& m : hp.st_mark) m = 0;
-        hp.pending.clear();
-        hp.evused = 0;
-        hp.ramp = (size_t)2 << 20;
-        hp.st_bytes_up = hp.st_bytes_down = hp.st_seconds = 0;
-        hp.st_chunks = hp.st_direct = 0;
+        if ((rc = hp_begin(hp))) return rc;
         if ((rc = ws_ensure(c, WS_X, sizeof(float) * T))) return rc;
         if (!bank_dev && (rc = ws_ensure(c, WS_BANK, bank_bytes))) return rc;
         if ((rc = ws_ensure(c, WS_Y, sizeof(float) * (size_t)C * T))) return rc;
@@ -2456,7 +2451,11 @@ int ss_stream_open(void** handle, const float* rirs, int32_t P, int32_t C, int32
     }
     // the first segment's two rows, and the row after them, are transformed now; every later row one whole segment ahead of its use
     for (int r = 0; r < 3; ++r)
-        if ((rc = stream_prepare_row(st, r, stream))) return rc;
+        if ((rc = stream_prepare_row(st, r, stream))) {
+            hipFree(d.Hs); hipFree(d.Xr); hipFree(d.xh);
+            delete st;
+            return rc;
+        }
     *handle = st;
     return SS_OK;
 }
