@@ -132,6 +132,17 @@ inline void merge_lpt_xcd(Plan& plan, int NP, int groups, std::vector<Task>& out
     auto before = [](const Task& a, const Task& b) { return a.row != b.row ? a.row < b.row : (a.j0 != b.j0 ? a.j0 < b.j0 : a.chan < b.chan); };
     std::merge(A.begin(), A.end(), B.begin(), B.end(), byt.begin(), before);
     if (!std::is_sorted(byt.begin(), byt.end(), before)) std::stable_sort(byt.begin(), byt.end(), before);   // (not expected)
+    // moving source: the tasks of one filter row stay together -- channel-major inside the row and keyed by the row's most expensive task
+    // (plan_seg_lpt, round 4: the second reader of a row's taps then finds them in its XCD's L2).  A fixed receiver has ONE row per channel
+    // read by every task: its list stays in time order.
+    static thread_local std::vector<int32_t> rowmax;
+    const bool pair_rows = n > 0 && byt.front().row != byt.back().row;
+    if (pair_rows) {
+        std::stable_sort(byt.begin(), byt.end(), [](const Task& a, const Task& b) { return a.row != b.row ? a.row < b.row : (a.chan != b.chan ? a.chan < b.chan : a.j0 < b.j0); });
+        rowmax.assign((size_t)byt.back().row + 1, 0);
+        for (const Task& t : byt) rowmax[(size_t)t.row] = std::max<int32_t>(rowmax[(size_t)t.row], cost(t));
+    }
+    auto key = [&](const Task& t) { return pair_rows ? (int)rowmax[(size_t)t.row] : cost(t); };
     int64_t total = 0;
     for (const Task& t : byt) total += cost(t);
     if (groups > 64) groups = 64;
@@ -146,7 +157,7 @@ inline void merge_lpt_xcd(Plan& plan, int NP, int groups, std::vector<Task>& out
         int g = total > 0 ? (int)((__int128)(acc + c / 2) * groups / total) : 0;
         if (g >= groups) g = groups - 1;
         gof[i] = g;
-        hist[(size_t)g * MAXCOST + c]++;
+        hist[(size_t)g * MAXCOST + key(byt[i])]++;
         gcount[g]++;
         acc += c;
     }
@@ -154,7 +165,7 @@ inline void merge_lpt_xcd(Plan& plan, int NP, int groups, std::vector<Task>& out
     for (int g = 0; g < groups; ++g)
         for (int c = MAXCOST - 1; c >= 0; --c) { int32_t& h = hist[(size_t)g * MAXCOST + c]; const int32_t k = h; h = run; run += k; }
     tmp.resize(n);
-    for (size_t i = 0; i < n; ++i) tmp[(size_t)hist[(size_t)gof[i] * MAXCOST + cost(byt[i])]++] = byt[i];
+    for (size_t i = 0; i < n; ++i) tmp[(size_t)hist[(size_t)gof[i] * MAXCOST + key(byt[i])]++] = byt[i];
     out.resize(n);
     int32_t next[64], end[64];
     int32_t off = 0;
