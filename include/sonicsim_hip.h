@@ -82,6 +82,14 @@ int ss_async_status(int32_t* code, int64_t* where, void* stream);
  * reference's fancy index (SonicSim_moving.py:89-90) -- no bounds array travels to the host. */
 int ss_plan_status_last(int32_t* out_of_range, int64_t* where, int32_t* too_irregular, void* stream);
 
+/* ss_convolve_moving_f32 with the schedule planned on the device AND this call's verdict returned by the call itself (round 4): status[3] =
+ * {out_of_range (1: an interp_index outside [0, P-2]; -1: the engine in use validated on the host before rendering, nothing to report),
+ * first sample of the offending 1024-sample tile, too_irregular (the schedule did not fit the planner's task buffer: nothing valid was rendered)}.
+ * One synchronisation, taken before the device context's lock is released -- unlike ss_plan_status_last no other thread's render can slip
+ * between the render and the read.  This is what ops.convolve_moving(validate=True) calls. */
+int ss_convolve_moving_checked_f32(const float* x, int64_t T, const float* rirs, int32_t P, int32_t C, int32_t L, const int64_t* idx,
+                                   const float* w, float* y, uint32_t flags, void* stream, int64_t* status);
+
 /* ---- how the render kernel's workgroups get their tasks (current device) --------------------------------------------------------
  * 1 (default): dynamic queues -- one queue per XCD holding that XCD's stretch of the LPT plan; every task (the first included) is taken
  * with an atomic ticket, one task ahead so that its round trip is never waited for.  A workgroup that gets onto the machine late --

@@ -1756,7 +1756,9 @@ int load_mod13(Ctx* c, bool dynq = false) {
 // the render engine shared by rows V / I+V / F
 int render(int mode, const float* x, int64_t T, const float* bank, int32_t P, int32_t C, int32_t L,
            const int64_t* seg_len_host, const int64_t* idx, const float* w, float* y, uint32_t flags, void* stream_,
-           const float* xdiv = nullptr /* device scalar: render with bank / *xdiv (deferred peak normalisation) */) {
+           const float* xdiv = nullptr /* device scalar: render with bank / *xdiv (deferred peak normalisation) */,
+           int64_t* status_out = nullptr /* [3]: THIS call's device-planner verdict {out_of_range (-1: validated on the host), where, too_irregular};
+                                            asking for it synchronises the stream before the context lock is released */) {
     if (T < 0 || P < 1 || C < 1 || L < 1) return fail(SS_EINVAL, "bad shape: T=%lld P=%d C=%d L=%d", (long long)T, P, C, L);
     if (T == 0) return SS_OK;
     if (!x || !bank || !y) return fail(SS_EINVAL, "NULL data pointer");
@@ -2191,6 +2193,15 @@ int render(int mode, const float* x, int64_t T, const float* bank, int32_t P, in
     }
     HIPCHK(hipGetLastError());
 
+    if (status_out) {
+        status_out[0] = -1; status_out[1] = 0; status_out[2] = 0;
+        if (dev_plan && c->async_status) {
+            int32_t h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            HIPCHK(hipMemcpyAsync(h, c->async_status, 32, hipMemcpyDeviceToHost, stream));
+            HIPCHK(hipStreamSynchronize(stream));
+            status_out[0] = h[3]; status_out[1] = (int64_t)h[4] * DTILE; status_out[2] = h[2];
+        }
+    }
     if (!dev) {
         hipEvent_t e_done;
         if ((rc = hp_event(hp, &e_done))) return rc;
@@ -2568,6 +2579,12 @@ int ss_host_alloc(void** out, int64_t bytes) {
 int ss_host_free(void* p) {
     if (p) HIPCHK(hipHostFree(p));
     return SS_OK;
+}
+
+int ss_convolve_moving_checked_f32(const float* x, int64_t T, const float* rirs, int32_t P, int32_t C, int32_t L, const int64_t* idx,
+                                   const float* w, float* y, uint32_t flags, void* stream, int64_t* status) {
+    if (!status) return fail(SS_EINVAL, "status is NULL");
+    return render(COEF_EXPLICIT, x, T, rirs, P, C, L, nullptr, idx, w, y, flags | SS_FLAG_ASYNC_PLAN, stream, nullptr, status);
 }
 
 int ss_set_task_queue(int dynamic) {

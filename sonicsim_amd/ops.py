@@ -225,10 +225,10 @@ def convolve_moving(x, rirs, idx, w, path=None, out=None, validate=True):
             # SonicSim_moving.py:89-90) and so does this; what changes is that no bounds array travels to the host and no host planner
             # sits between the kernels (0.30 -> 0.24 ms per config-2 render).  A schedule too irregular for the device planner's task
             # buffer falls through to the host-planned path below.
-            _lib.check(lib.ss_convolve_moving_f32(_ptr(x), T, _ptr(rirs), P, C, L, _ptr(idx), _ptr(w), _ptr(y),
-                                                  flags | _lib.FLAG_DEVICE_PTR | _lib.FLAG_ASYNC_PLAN, _stream_ptr(x)))
-            oor, where, irregular = ctypes.c_int32(0), ctypes.c_int64(0), ctypes.c_int32(0)
-            _lib.check(lib.ss_plan_status_last(ctypes.byref(oor), ctypes.byref(where), ctypes.byref(irregular), _stream_ptr(x)))   # THIS call's outcome
+            st3 = (ctypes.c_int64 * 3)()
+            _lib.check(lib.ss_convolve_moving_checked_f32(_ptr(x), T, _ptr(rirs), P, C, L, _ptr(idx), _ptr(w), _ptr(y),
+                                                          flags | _lib.FLAG_DEVICE_PTR, _stream_ptr(x), st3))      # render + THIS call's verdict, one lock
+            oor, where, irregular = ctypes.c_int32(int(st3[0])), ctypes.c_int64(int(st3[1])), ctypes.c_int32(int(st3[2]))
             if oor.value < 0:
                 return y                          # the library ignored the flag (another engine): it validated on the host before rendering
             if oor.value or irregular.value:

@@ -131,3 +131,48 @@ def test_validating_call_is_not_fooled_by_an_older_unpolled_error():
         ops.convolve_moving(x, bank, db, dw, path="asm")                       # invalid: raises although the latched word was set before
     assert torch.equal(ops.convolve_moving(x, bank, di, dw, path="asm"), good)
     ops.async_status()
+
+
+def test_two_threads_each_get_their_own_verdict():
+    """ss_convolve_moving_checked_f32 renders and reads the planner's words under ONE lock of the device context: two host threads rendering
+    on the same device -- one valid schedule, one out of range -- never see each other's outcome (ss_plan_status_last could)"""
+    import threading
+    T, P, C, L = 60000, 6, 1, 9000
+    ops, rng, dev, x, bank = _setup(T, P, C, L, 6)
+    idx = np.minimum(np.arange(T) // 12000, P - 2).astype(np.int64)
+    w = rng.random(T).astype(np.float32)
+    bad = idx.copy()
+    bad[30000:30002] = P - 1
+    di, db, dw = torch.from_numpy(idx).to(dev), torch.from_numpy(bad).to(dev), torch.from_numpy(w).to(dev)
+    good = ops.convolve_moving(x, bank, di, dw, path="asm")
+    torch.cuda.synchronize()
+    wrong = []
+
+    def valid():
+        s = torch.cuda.Stream()
+        with torch.cuda.stream(s):
+            for _ in range(40):
+                try:
+                    if not torch.equal(ops.convolve_moving(x, bank, di, dw, path="asm"), good):
+                        wrong.append("bits")
+                except ValueError:
+                    wrong.append("valid call raised")
+
+    def invalid():
+        s = torch.cuda.Stream()
+        with torch.cuda.stream(s):
+            for _ in range(40):
+                try:
+                    ops.convolve_moving(x, bank, db, dw, path="asm")
+                    wrong.append("invalid call passed")
+                except ValueError:
+                    pass
+
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)        # the latch (first error wins) may hold the other thread's error: a warning, not a verdict
+        th = [threading.Thread(target=valid), threading.Thread(target=invalid)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+    ops.async_status()
+    assert not wrong, wrong[:5]
