@@ -151,8 +151,15 @@ struct HostPipe {
                                        // enqueued, results enqueued, everything copied out (ss_host_path_stats entries 6..13)
 };
 
+static void hp_destroy(HostPipe& h);
+static int hp_ensure_build(HostPipe& h);
 static int hp_ensure(HostPipe& h) {
     if (h.up) return SS_OK;
+    const int rc = hp_ensure_build(h);
+    if (rc) hp_destroy(h);           // (out of pinned memory half way: nothing half-built survives, the next call starts over)
+    return rc;
+}
+static int hp_ensure_build(HostPipe& h) {
     HIPCHK(hipStreamCreateWithFlags(&h.up, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&h.down, hipStreamNonBlocking));
     for (int i = 0; i < HostPipe::NUP; ++i) {
