@@ -859,6 +859,9 @@ def run_hostpath(args, dev):
     same = bool(np.array_equal(y1.numpy(), want_h))
     t_full = best(dropin)
     st_full = ops.host_path_stats()
+    scratch_h = np.empty_like(bank)
+    t_memcpy = best(lambda: np.copyto(scratch_h, bank), n=3)[0]       # what ONE host thread moves on this box (the staging copy is host-memory bound)
+    del scratch_h
     t_xy = best(lambda: ops.convolve_moving_seg(sc.x, dbank, seg, host_io=True))
     y2 = ops.convolve_moving_seg(sc.x, dbank, seg, host_io=True)
     po = ops.pinned_empty(want_h.shape)
@@ -872,6 +875,9 @@ def run_hostpath(args, dev):
             "ms": t_full[0] * 1e3, "ms_median": t_full[1] * 1e3, "rendered_audio_sec_per_sec": audio_s / t_full[0],
             "same_bits_as_the_resident_render": same and bool(np.array_equal(y2, want_h)),
             "bytes_up": st_full["bytes_up"], "bytes_down": st_full["bytes_down"], "bank_chunks": st_full["chunks"], "copy_threads": st_full["threads"],
+            "stage_marks_ms_of_the_last_call": dict(zip(["staging_ready", "x_on_its_way", "plan_built", "spectra_launched", "bank_and_launches_enqueued",
+                                                         "results_enqueued", "everything_copied_out"], st_full["marks_ms"])),
+            "host_memcpy_one_thread_GBs": bank.nbytes / t_memcpy / 1e9,
             "pcie_pinned_dma_reference": {"up_ms": t_up * 1e3, "up_GBs": bank.nbytes / t_up / 1e9, "down_ms": t_dn * 1e3,
                                           "note": "one pinned hipMemcpyAsync of the bank / of y (torch), the link's ceiling for these bytes"},
             "x_pcie_time_of_the_bytes_moved": t_full[0] / (t_up * nb / bank.nbytes),
