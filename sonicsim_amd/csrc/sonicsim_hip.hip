@@ -2035,7 +2035,8 @@ int render(int mode, const float* x, int64_t T, const float* bank, int32_t P, in
             }
             if (g13 || g14) {
                 hipLaunchKernelGGL(k_xspec13, dim3(M + 1), dim3(NT13), 0, stream, dx, T, (const c32*)c->consts13, (c32*)c->ws[WS_XS], M,
-                                   knob("SS_NO_ZFILL") ? (float*)nullptr : dy /* (tuning build: spectra kernel without its zero fill -- results WRONG) */,
+                                   // a static source on the assembly engine is STORED (one task per channel and output block): no zero fill
+                                   (knob("SS_NO_ZFILL") /* (tuning build: results WRONG) */ || (g14 && mode == COEF_FIXED)) ? (float*)nullptr : dy,
                                    (int64_t)C * T, (g13 || qgroups) ? (int*)c->ws[WS_CNT] : (int*)nullptr, g13 ? 1 : qgroups + 1,
                                    g13 ? 0 : qinit, xdiv, rs, xspec_stages_plan ? (const uint4*)pin->host : (const uint4*)nullptr,
                                    xspec_stages_plan ? (uint4*)c->ws[WS_PLAN] : (uint4*)nullptr, xspec_stages_plan ? (int)blob16 : 0,
@@ -2303,7 +2304,7 @@ int render_scene(int nsrc, const float* const* xs, int64_t T, const float* const
             tab.x[s] = xs[s];
             tab.xdiv[s] = divisors ? divisors[s] : nullptr;
             tab.Xs[s] = (c32*)((char*)c->ws[WS_XS] + xs_one * (size_t)s);
-            tab.y[s] = ys[s];
+            tab.y[s] = Ps[s] > 1 ? ys[s] : nullptr;       // static sources are stored by the render kernel, not added onto zeros
         }
         hipLaunchKernelGGL(k_xspec13_multi, dim3(M + 1, nsrc), dim3(NT13), 0, stream, tab, T, (const c32*)c->consts13, M, (int64_t)C * T,
                            qgroups ? (int*)c->ws[WS_CNT] : (int*)nullptr, qgroups + 1, 0, (const uint4*)pin->host, (uint4*)c->ws[WS_PLAN], (int)blob16);

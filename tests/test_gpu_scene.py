@@ -135,3 +135,21 @@ def test_scene_renderer_prefetched_provider_same_bits(gpu):
     np.random.seed(100)
     mix_s, gains_s = pipeline.SceneRenderer(specs[0], gpu).render(specs[0], seed=11, sirs=(1.5,), snr=12.0)      # default: synchronous, Python floats
     assert len(g) == 5 and torch.equal(mix_s, base[0][0]) and np.allclose(gains_s, g, rtol=0, atol=0)
+
+
+def test_static_render_is_stored_not_added(gpu):
+    """a static source on the assembly engine has one task per (channel, output block): the kernel STORES y and the spectra kernel skips the
+    zero fill -- a buffer full of NaN comes back complete and equal to a fresh render, for lengths that end inside a block / a hop"""
+    from oracle import moving as O
+    from sonicsim_amd import ops
+    rng = np.random.default_rng(11)
+    for (T, C, L) in ((16000, 1, 4096), (70001, 3, 8200), (4095, 2, 9000), (300000, 8, 48000)):
+        x = torch.from_numpy((rng.standard_normal(T) * 0.1).astype(np.float32)).to(gpu)
+        h = torch.from_numpy((rng.standard_normal((C, L)) * np.exp(-4.0 * np.arange(L) / L)[None, :]).astype(np.float32)).to(gpu)
+        want = ops.convolve_fixed(x, h, path="asm")
+        out = torch.full((C, T), float("nan"), dtype=torch.float32, device=gpu)
+        got = ops.convolve_fixed(x, h, path="asm", out=out)
+        assert got.data_ptr() == out.data_ptr() and torch.isfinite(got).all()
+        assert torch.equal(got, want)
+        ref = O.convolve_fixed_receiver(x.cpu().numpy(), h.cpu().numpy())
+        assert O.rel_rms(got.cpu().numpy(), ref) <= 1e-4
