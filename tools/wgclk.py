@@ -8,7 +8,8 @@ sys.path.insert(0, ".")
 from sonicsim_amd import ops, synth
 ops.init(0)
 dev = torch.device("cuda:0")
-sc = synth.make_scene("cfg2", scene=0)
+cfg = sys.argv[1] if len(sys.argv) > 1 else "cfg2"
+sc = synth.make_scene(cfg, scene=0)
 seg = synth.scene_segments(sc, 0)
 bank = ops.rir_bank_synth(sc.delay, sc.dgain, sc.L, sc.fs, sc.rt60, sc.bank_seed, device=dev)
 ops.peak_normalize_(bank)
@@ -22,6 +23,7 @@ ok = st > 0
 st, en = st[ok], en[ok]
 t0 = st.min()
 us = lambda v: v / 100.0
+print(cfg, "mean busy / span = %.4f (idle %.1f us of the span per workgroup on average)" % ((en - st).mean() / (en.max() - t0), us(en.max() - t0 - (en - st).mean())))
 print("workgroups", ok.sum(), " span us %.1f" % us(en.max() - t0))
 print("start: median +%.1f  p90 +%.1f  max +%.1f us" % (us(np.median(st) - t0), us(np.percentile(st, 90) - t0), us(st.max() - t0)))
 print("end  : min %.1f  p10 %.1f  median %.1f  p90 %.1f  max %.1f us" % tuple(us(v - t0) for v in (en.min(), np.percentile(en, 10), np.median(en), np.percentile(en, 90), en.max())))
