@@ -887,6 +887,52 @@ def run_hostpath(args, dev):
                    "rendered (static task lists) while chunk k + 1 is on the wire; finished stretches of y travel back at once"}
 
 
+def run_batched(args, dev):
+    """Information, never `value`: THREE different config-2 renders (the three moving speakers of a SonicSet sample, SonicSet.py:61-79) through the
+    batched entry point -- one spectra launch + ONE persistent render launch (ss_convolve_scene_f32).  5 280 tasks instead of 1 760 fill the end
+    of the launch better and one spectra kernel serves three renders."""
+    import torch
+
+    from sonicsim_amd import ops, synth
+    xs, banks, segs = [], [], []
+    for s in range(3):
+        sc = synth.make_scene("cfg2", scene=s)
+        segs.append(synth.scene_segments(sc, s))
+        bank = ops.rir_bank_synth(sc.delay, sc.dgain, sc.L, sc.fs, sc.rt60, sc.bank_seed, device=dev)
+        ops.peak_normalize_(bank)
+        banks.append(bank)
+        xs.append(torch.from_numpy(sc.x).to(dev))
+    outs = [torch.empty((sc.C, sc.T), dtype=torch.float32, device=dev) for _ in range(3)]
+    sep = [ops.convolve_moving_seg(x, b, sg) for x, b, sg in zip(xs, banks, segs)]
+    got = ops.convolve_scene(xs, banks, segs, outs=outs)
+    same = all(torch.equal(a, b) for a, b in zip(got, sep))
+    K = 20
+
+    def window():
+        for _ in range(3):
+            ops.convolve_scene(xs, banks, segs, outs=outs)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(K):
+            ops.convolve_scene(xs, banks, segs, outs=outs)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / K
+
+    for _ in range(3):
+        window()
+    ts = sorted(window() for _ in range(5))
+    ms = ts[len(ts) // 2] * 1e3
+    audio_s = sc.T / sc.fs
+    nbytes = 3 * algorithmic_bytes(sc.T, sc.P, sc.C, sc.L)
+    return {"workload": "3 x cfg2 (three different moving sources: own dry signal, bank and trajectory each) in ONE ss_convolve_scene_f32 call",
+            "ms_per_call": ms, "ms_per_render": ms / 3, "rendered_audio_sec_per_sec": 3 * audio_s / (ms * 1e-3),
+            "same_bits_as_three_separate_renders": bool(same),
+            "roofline": {"bound": "hbm", "achieved": nbytes / (ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": nbytes / (ms * 1e-3) / 1e9 / 8000.0,
+                         "traffic": None, "note": "WHOLE CALL (spectra launch + render launch + the boundary between them) over 3 x 353.28 MB, wall clock "
+                                                  "over 20 calls, median of 5 windows -- not a kernel-only figure"},
+            "windows_ms_per_call": [t * 1e3 for t in ts]}
+
+
 def secondary_legs(args, rank, local_rank, dev, primary):
     """The other BASELINE.json configurations in the same driver-run line (N = 1): cfg5 (largest single-GPU render), cfg4's per-GPU
     share (64 full scenes), cfg1 (plumbing), and the host-pointer path of cfg2.  Each leg is a dict with its own config.workload,
@@ -925,9 +971,9 @@ def secondary_legs(args, rank, local_rank, dev, primary):
         a.cfg2_cpu_seconds = cb.get("seconds_measured") if "whole config" in str(cb.get("sample", "")) else None
         return run_scenes(a, rank, local_rank, 1, dev)
 
-    want = [w.strip() for w in (args.legs or "host,cfg5,cfg4,cfg1").split(",") if w.strip()]
+    want = [w.strip() for w in (args.legs or "host,cfg5,cfg4,cfg1,batch").split(",") if w.strip()]
     table = {"host": ("cfg2_end_to_end_host", lambda: run_hostpath(args, dev)), "cfg5": ("cfg5", cfg5), "cfg4": ("cfg4_per_gpu_share", cfg4),
-             "cfg1": ("cfg1", lambda: run_cfg1(args, dev))}
+             "cfg1": ("cfg1", lambda: run_cfg1(args, dev)), "batch": ("cfg2_three_renders_one_launch", lambda: run_batched(args, dev))}
     for w in want:
         if w in table:
             guarded(*table[w])
@@ -972,7 +1018,7 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="default run (cfg2, N = 1) without the legs for cfg5 / cfg4 / cfg1 / the host-pointer path")
     ap.add_argument("--scenes", type=int, default=None, help="cfg3 / cfg4: total number of scenes over all ranks (default steps x ranks); need not divide")
     ap.add_argument("--scene-config", default=None, help="cfg3 / cfg4: shapes of a scene's sources (default cfg2; 'tiny' for dry runs)")
-    ap.add_argument("--legs", default=None, help="secondary legs of the default run, comma separated, in this order: host,cfg5,cfg4,cfg1 (default: all)")
+    ap.add_argument("--legs", default=None, help="secondary legs of the default run, comma separated, in this order: host,cfg5,cfg4,cfg1,batch (default: all)")
     ap.add_argument("--lib", default=os.environ.get("BENCH_LIB"), help="measurement tools: another build of the library (tuning / A-B variants)")
     args = ap.parse_args()
     if args.lib:
