@@ -31,8 +31,13 @@ ranks itself (torch.distributed.run, one process per GPU) and refuses when the n
   secondary    -- (round 4; N = 1, config 2) the other BASELINE.json configurations and the host-pointer path in the SAME line, each a dict with its
                   own config.workload, ms_per_step, roofline and cpu_baseline: cfg2_end_to_end_host (NumPy / CPU tensors in, CPU tensor out through
                   SonicSim_moving.interpolate_moving_audio, with the pinned-DMA time of the same bytes measured beside it -- PCIe inclusive, never
-                  `value`), cfg5, cfg4_per_gpu_share (64 full scenes), cfg1.  --no-secondary / --legs host,cfg5,cfg4,cfg1 select them.
+                  `value`), cfg5, cfg4_per_gpu_share (64 full scenes), cfg1, and -- information -- three config-2 renders in ONE launch.
+                  --no-secondary / --legs host,cfg5,cfg4,cfg1,batch select them.
   roofline.compute -- the arithmetic of the planned transforms over the kernel time against the fp32 vector peak (the bound the kernel lives under).
+  roofline.traffic -- HBM-side bytes per launch of the render kernel measured by THIS run (N = 1, default protocol): two more processes of this
+                  script under `rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes, calibrated on kernels of known byte
+                  counts in the same passes; ~4 s per workload); the committed profiles/pmc_summary.json only if rocprofv3 is missing or fails
+                  (`traffic_source` says which); --no-live-traffic skips the passes.
 The oracle is used here only as the timed CPU baseline and as the checker.
 """
 import argparse
@@ -268,6 +273,62 @@ def cpu_baselines(sc, seg, bank_h, budget_s, all_cores=True):
 
 
 # ------------------------------------------------------------------------------------------------ config 2 (headline)
+def live_traffic(config, bank_bytes, timeout_s=300):
+    """HBM-side bytes per launch of k_os13_asm measured NOW, by this run: two more processes of this script (3 steps, no CPU legs, no secondary
+    legs) under `rocprofv3 --kernel-trace --pmc FETCH_SIZE` and `... --pmc WRITE_SIZE` -- SEPARATE passes, counters in KiB, FETCH_SIZE calibrated
+    on k_absmax (reads exactly the bank) and WRITE_SIZE on k_divide (writes exactly the bank) in the same passes, as MI355X_MICROARCH.md's HBM
+    section prescribes (gfx950 under-reports coalesced streaming reads by 2x).  Returns (bytes or None, how / why not, details)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    from collections import defaultdict
+    if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or os.environ.get("BENCH_IN_PMC"):
+        return None, "this process already runs under a profiler", None
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found", None
+    tmp = tempfile.mkdtemp(prefix="bench_pmc_", dir="/tmp")
+    env = dict(os.environ, BENCH_PREWARM_MS="0", BENCH_CALIB="1", BENCH_NO_AB="1", BENCH_IN_PMC="1", TMPDIR="/tmp")
+    avg = {}
+    t0 = time.perf_counter()
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, ctr)
+            cmd = [exe, "--kernel-trace", "--pmc", ctr, "-d", d, "-o", "pmc", "-f", "csv", "--", sys.executable, os.path.abspath(__file__),
+                   "--no-secondary", "--steps", "3", "--warmup", "1", "--cpu-seconds", "0", "--config", config, "--windows", "2", "--event-windows", "1"]
+            r = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=timeout_s)
+            if r.returncode != 0:
+                return None, f"rocprofv3 --pmc {ctr} exited with {r.returncode}: {r.stderr.decode(errors='replace')[-300:]}", None
+            per = defaultdict(list)
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if row.get("Counter_Name") == ctr:
+                        name = row["Kernel_Name"]
+                        for k in ("k_os13_asm", "k_absmax", "k_divide", "k_xspec13"):
+                            if k in name:
+                                per[k].append(float(row["Counter_Value"]))
+            avg[ctr] = {k: (sum(v) / len(v), len(v)) for k, v in per.items()}
+    except Exception as e:                                   # noqa: BLE001 -- a profiler problem must not take the bench line down
+        return None, f"{type(e).__name__}: {e}"[:300], None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    try:
+        fcal = bank_bytes / (avg["FETCH_SIZE"]["k_absmax"][0] * 1024.0)
+        wcal = bank_bytes / (avg["WRITE_SIZE"]["k_divide"][0] * 1024.0)
+        f_raw, nf = avg["FETCH_SIZE"]["k_os13_asm"]
+        w_raw, nw = avg["WRITE_SIZE"]["k_os13_asm"]
+    except (KeyError, ZeroDivisionError) as e:
+        return None, f"counter rows missing: {e!r}", None
+    fetch, write = f_raw * 1024.0 * fcal, w_raw * 1024.0 * wcal
+    det = {"fetch_bytes": fetch, "write_bytes": write, "fetch_raw_bytes": f_raw * 1024.0, "write_raw_bytes": w_raw * 1024.0,
+           "fetch_calibration_on_k_absmax": fcal, "write_calibration_on_k_divide": wcal, "launches_counted": [nf, nw],
+           "seconds": time.perf_counter() - t0}
+    return fetch + write, ("measured by THIS run: two more processes of this script (3 steps) under rocprofv3 --kernel-trace --pmc FETCH_SIZE / "
+                           "--pmc WRITE_SIZE (separate passes), FETCH calibrated on k_absmax, WRITE on k_divide in the same passes"), det
+
+
 def run_cfg2(args, rank, local_rank, world, dev):
     import numpy as np
     import torch
@@ -415,9 +476,14 @@ def run_cfg2(args, rank, local_rank, world, dev):
     avg_launch_ms = ms_os / max(1, n_os)
     bytes_per_launch = render_bytes / max(1.0, launches_per_render)
     achieved = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
-    traffic, traffic_src = None, None
+    traffic, traffic_src, traffic_det = None, None, None
     pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")     # written by tools/profile.sh (separate --pmc passes)
-    if os.path.exists(pmc):
+    if world == 1 and not getattr(args, "no_live_traffic", False):
+        traffic, traffic_src, traffic_det = live_traffic(args.config, 4 * sc.P * sc.C * sc.L)
+        if traffic is None:
+            traffic_det = {"live_measurement_failed": traffic_src}
+            traffic_src = None
+    if traffic is None and os.path.exists(pmc):
         try:
             js = json.load(open(pmc))
             # counters are per workload: the committed passes ran config 2; another config reports null unless its own passes exist
@@ -468,7 +534,7 @@ def run_cfg2(args, rank, local_rank, world, dev):
                                "of the fresh process",
                    "prewarm_ms": prewarm_ms, "prewarm_steps": prewarm_steps},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "traffic_details": traffic_det,
                      "kernel": "k_os13_asm (hand-scheduled gfx950 assembly: row-stationary partitioned overlap-save, B=4096, persistent, "
                                "one launch per render)",
                      "compute": {"flops_per_launch": flops / max(1.0, launches_per_render), "unit": "TFLOP/s",
@@ -1015,6 +1081,8 @@ def main():
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--windows", type=int, default=7, help="timed K-step windows of the sustained section (value = the median window)")
     ap.add_argument("--event-windows", type=int, default=None)
+    ap.add_argument("--no-live-traffic", action="store_true", help="roofline.traffic from the committed profiles/pmc_summary.json instead of two rocprofv3 "
+                                                                   "--pmc passes of this run (+20-40 s)")
     ap.add_argument("--no-secondary", action="store_true", help="default run (cfg2, N = 1) without the legs for cfg5 / cfg4 / cfg1 / the host-pointer path")
     ap.add_argument("--scenes", type=int, default=None, help="cfg3 / cfg4: total number of scenes over all ranks (default steps x ranks); need not divide")
     ap.add_argument("--scene-config", default=None, help="cfg3 / cfg4: shapes of a scene's sources (default cfg2; 'tiny' for dry runs)")
@@ -1026,6 +1094,8 @@ def main():
         _lib.use_library(args.lib)
     if args.cpu_positions == 0:
         args.cpu_seconds = 0
+    if args.no_secondary or args.config in ("cfg3", "cfg4"):
+        args.no_live_traffic = True              # (the measurement tools' short runs: counters come from tools/profile.sh there)
 
     import torch
 
