@@ -273,7 +273,7 @@ def cpu_baselines(sc, seg, bank_h, budget_s, all_cores=True):
 
 
 # ------------------------------------------------------------------------------------------------ config 2 (headline)
-def live_traffic(config, bank_bytes, timeout_s=300):
+def live_traffic(config, bank_bytes, timeout_s=120):
     """HBM-side bytes per launch of k_os13_asm measured NOW, by this run: two more processes of this script (3 steps, no CPU legs, no secondary
     legs) under `rocprofv3 --kernel-trace --pmc FETCH_SIZE` and `... --pmc WRITE_SIZE` -- SEPARATE passes, counters in KiB, FETCH_SIZE calibrated
     on k_absmax (reads exactly the bank) and WRITE_SIZE on k_divide (writes exactly the bank) in the same passes, as MI355X_MICROARCH.md's HBM
