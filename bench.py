@@ -289,7 +289,10 @@ def live_traffic(config, bank_bytes, timeout_s=120):
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
         return None, "rocprofv3 not found", None
-    tmp = tempfile.mkdtemp(prefix="bench_pmc_", dir="/tmp")
+    try:
+        tmp = tempfile.mkdtemp(prefix="bench_pmc_", dir="/tmp")
+    except OSError as e:
+        return None, f"no scratch directory: {e}", None
     env = dict(os.environ, BENCH_PREWARM_MS="0", BENCH_CALIB="1", BENCH_NO_AB="1", BENCH_IN_PMC="1", TMPDIR="/tmp")
     avg = {}
     t0 = time.perf_counter()
