@@ -106,9 +106,10 @@ int ss_set_task_queue(int dynamic);
  * chunks of whole trajectory positions: the rows of chunk k are rendered while chunk k + 1 is on the wire, and every stretch of the output
  * that no later chunk touches travels back at once.  Same bits as the device-pointer render.  Buffers the caller pinned itself
  * (ss_host_alloc, hipHostMalloc, hipHostRegister) are recognised and moved by DMA directly, without the staging copy.
- * ss_set_host_pipe: copy threads (0 = keep; default 4: more only contend for the memory system, profiles/r04a), bytes per staging slot (default 16 MiB, 6 up + 4 down),
+ * ss_set_host_pipe: copy threads (0 = keep; default 4: more only contend for the memory system, profiles/r04a), bytes per upload slot (default 32 MiB, 6 of them; 4 download slots of <= 4 MiB),
  * bytes per bank chunk (default 24 MiB, at most 16 chunks), bind (-1 = keep; 2 = default: the copy threads follow the caller's pages -- bound to the
- * NUMA node the array being staged lives on (move_pages query), so the staging copy reads locally; 0 = left to the scheduler (measured bimodal:
+ * NUMA node the array being staged lives on (move_pages query), so the staging copy reads locally, ONE THREAD PER LAST-LEVEL CACHE of that node (sysfs
+ * cache/index3/id: four threads on one CCD share its ~55 GB/s link and stage a 307 MB bank in 5.7 instead of 3.1 ms, profiles/r04al); 0 = left to the scheduler (measured bimodal:
  * 6.45 or 8.5 ms per config-2 render from run to run); 1 = bound to the CPUs next to the GPU (sysfs local_cpulist; slower when the caller's arrays
  * live on the other socket: 8.4 ms, profiles/r04d)) -- current device.
  * ss_host_path_stats: {seconds inside the last host-pointer render call, bytes up, bytes down, bank chunks, direct (pinned) transfers,
