@@ -157,6 +157,8 @@ struct HostPipe {
         int rows;
     };
     std::deque<Pending> pending;
+    std::vector<std::vector<int>> node_cpus;                 // per NUMA node: its CPUs ...
+    std::vector<std::vector<std::vector<int>>> node_groups;  // ... and those by last-level cache (filled on first use, hp_follow)
     // statistics of the last host-pointer render (ss_host_path_stats)
     double st_bytes_up = 0, st_bytes_down = 0, st_seconds = 0;
     int st_chunks = 0, st_direct = 0;
@@ -273,13 +275,18 @@ static void hp_llc_groups(const std::vector<int>& cpus, std::vector<std::vector<
 // bind == 2: the workers follow the pages of the array that is about to be staged
 static void hp_follow(HostPipe& h, const void* p, size_t bytes) {
     if (h.bind != 2 || h.pool.th.empty()) return;
+    if (bytes < ((size_t)8 << 20) && h.pool.bound_node >= 0) return;      // a small array (the dry signal) does not move the threads off the bank's node
     int node = hp_page_node(p);
     if (node < 0 && bytes > 4096) node = hp_page_node((const char*)p + bytes / 2);
     if (node < 0 || node == h.pool.bound_node) return;
-    std::vector<int> cpus;
-    if (!hp_node_cpus(node, cpus)) return;
-    h.pool.cpus.swap(cpus);
-    hp_llc_groups(h.pool.cpus, h.pool.groups);
+    // (CPU list and cache groups of a node are read from sysfs once: a caller whose arrays alternate between the sockets flips per call)
+    if ((size_t)node >= h.node_cpus.size()) { h.node_cpus.resize((size_t)node + 1); h.node_groups.resize((size_t)node + 1); }
+    if (h.node_cpus[(size_t)node].empty()) {
+        if (!hp_node_cpus(node, h.node_cpus[(size_t)node])) return;
+        hp_llc_groups(h.node_cpus[(size_t)node], h.node_groups[(size_t)node]);
+    }
+    h.pool.cpus = h.node_cpus[(size_t)node];
+    h.pool.groups = h.node_groups[(size_t)node];
     h.pool.apply_affinity();
     h.pool.bound_node = node;
 }
