@@ -222,6 +222,8 @@ struct PlanDevArgs {
     int32_t* bins;     // [groups * 4096] counting-sort bins
     int32_t* out;      // header (16 bytes: ntasks, 0, 0, 0) + Task[cap_rows * C]
     int32_t* status;   // [0] code (1 = interp_index out of range, 2 = plan capacity exceeded), [1] tile / count, latched
+    int32_t* status_host;   // pinned host mirror of THIS run's words {out of range, tile, too irregular} (null: nobody asked): the validating call
+                            // reads it after its stream synchronisation instead of paying a device-to-host copy of 32 bytes
 };
 
 __device__ inline int32_t ld_agent(const int32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -389,6 +391,12 @@ __global__ __launch_bounds__(1024) void k_plan_explicit(PlanDevArgs a) {
         }
     }
     if (tid == 0) { a.out[0] = N * a.C; a.out[1] = 0; a.out[2] = 0; a.out[3] = 0; }
+    if (tid == 0 && a.status_host) {               // (thread 0 wrote all three words itself)
+        a.status_host[0] = a.status[3];
+        a.status_host[1] = a.status[4];
+        a.status_host[2] = a.status[2];
+        __threadfence_system();
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1562,6 +1570,7 @@ struct Ctx {
     int num_cu = 0;
     bool last_dev_planned = false;        // the last render() on this device planned its schedule on the device (ss_plan_status_last is about it)
     int32_t* async_status = nullptr;      // device: {code, where} latched by k_plan_explicit (SS_FLAG_ASYNC_PLAN), read by ss_async_status
+    int32_t* status_pin = nullptr;        // pinned host words the planner mirrors this run's verdict into (ss_convolve_moving_checked_f32)
     HostPipe pipe;          // host-pointer mode: pinned staging rings, copy streams, copy threads (hostpipe.h)
     std::vector<Task> chunk_tmp;
     std::mutex mu;          // one lock per device context: entry points are re-entrant per device (one host thread per GPU works)
@@ -1892,6 +1901,14 @@ int render(int mode, const float* x, int64_t T, const float* bank, int32_t P, in
         pa.rcount = (int32_t*)(base + o_rc); pa.rtask = (int32_t*)(base + o_rt); pa.keys = (unsigned long long*)(base + o_keys); pa.bins = (int32_t*)(base + o_bins);
         pa.out = dplan_out = (int32_t*)c->ws[WS_DTASKS];
         pa.status = c->async_status;
+        pa.status_host = nullptr;
+        if (status_out) {
+            if (!c->status_pin) HIPCHK(hipHostMalloc((void**)&c->status_pin, 64, hipHostMallocDefault));
+            c->status_pin[0] = c->status_pin[1] = c->status_pin[2] = -2;       // (-2: the planner has not reported)
+            void* dp = nullptr;
+            HIPCHK(hipHostGetDevicePointer(&dp, c->status_pin, 0));
+            pa.status_host = (int32_t*)dp;
+        }
         hipLaunchKernelGGL(k_plan_explicit, dim3(1), dim3(1024), 0, stream, pa);
         HIPCHK(hipGetLastError());
         c->plan.tasks[0].clear();
@@ -2197,10 +2214,15 @@ int render(int mode, const float* x, int64_t T, const float* bank, int32_t P, in
     if (status_out) {
         status_out[0] = -1; status_out[1] = 0; status_out[2] = 0;
         if (dev_plan && c->async_status) {
-            int32_t h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            HIPCHK(hipMemcpyAsync(h, c->async_status, 32, hipMemcpyDeviceToHost, stream));
             HIPCHK(hipStreamSynchronize(stream));
-            status_out[0] = h[3]; status_out[1] = (int64_t)h[4] * DTILE; status_out[2] = h[2];
+            volatile int32_t* sp = c->status_pin;
+            if (sp && sp[0] != -2) {                // the planner's pinned mirror (no copy to wait for)
+                status_out[0] = sp[0]; status_out[1] = (int64_t)sp[1] * DTILE; status_out[2] = sp[2];
+            } else {
+                int32_t h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                HIPCHK(hipMemcpy(h, c->async_status, 32, hipMemcpyDeviceToHost));
+                status_out[0] = h[3]; status_out[1] = (int64_t)h[4] * DTILE; status_out[2] = h[2];
+            }
         }
     }
     if (!dev) {
@@ -2388,6 +2410,7 @@ int ss_shutdown(void) {
         hp_destroy(c->pipe);
         for (int i = 0; i < WS_COUNT; ++i) if (c->ws[i]) hipFree(c->ws[i]);
         if (c->async_status) hipFree(c->async_status);
+        if (c->status_pin) hipHostFree(c->status_pin);
         for (auto& p : c->ring) { if (p.host) hipHostFree(p.host); if (p.ev) hipEventDestroy(p.ev); }
         for (auto& e : c->evs) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
         for (auto& e : c->ev_pool) hipEventDestroy(e);

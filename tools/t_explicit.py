@@ -1,0 +1,28 @@
+"""GPU box: the explicit-schedule entry point (row V: convolve_moving_receiver(x, rirs, idx, w), SonicSim_moving.py:63-96) at config-2 shapes -- per-call time of
+the validating default, the asynchronous form and the fused implicit form; run under `rocprofv3 --kernel-trace --stats` for the per-kernel split (round 4).
+usage: python tools/t_explicit.py"""
+import sys, time, json
+import numpy as np, torch
+sys.path.insert(0, ".")
+from oracle import moving as O
+from sonicsim_amd import ops, synth
+ops.init(0)
+dev = torch.device("cuda:0")
+sc = synth.make_scene("cfg2", 0); seg = synth.scene_segments(sc, 0)
+bank = ops.rir_bank_synth(sc.delay, sc.dgain, sc.L, sc.fs, sc.rt60, sc.bank_seed, device=dev); ops.peak_normalize_(bank)
+x = torch.from_numpy(sc.x).to(dev)
+idx, w = O.expand_segments(seg)
+di, dw = torch.from_numpy(idx).to(dev), torch.from_numpy(w).to(dev)
+out = torch.empty((sc.C, sc.T), dtype=torch.float32, device=dev)
+def best(fn, k=50):
+    for _ in range(10): fn()
+    torch.cuda.synchronize(); ts = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        for _ in range(k): fn()
+        torch.cuda.synchronize(); ts.append((time.perf_counter() - t0) / k)
+    return round(min(ts) * 1e3, 4)
+r = {"implicit_seg_ms": best(lambda: ops.convolve_moving_seg(x, bank, seg, out=out)),
+     "explicit_async_ms": best(lambda: ops.convolve_moving(x, bank, di, dw, out=out, validate=False)),
+     "explicit_validating_ms": best(lambda: ops.convolve_moving(x, bank, di, dw, out=out))}
+print(json.dumps(r), flush=True)
