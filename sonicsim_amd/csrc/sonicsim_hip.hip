@@ -269,6 +269,20 @@ __global__ __launch_bounds__(1024) void k_plan_explicit(PlanDevArgs a) {
     __shared__ int oor_tile;               // first tile of THIS call with an index out of range (status[3..4]: per call, not latched)
     const int tid = threadIdx.x, nt = blockDim.x;
     if (tid == 0) oor_tile = INT32_MAX;
+    // round 4: the planner's scratch arrays live in LDS whenever they fit (they do at every BASELINE.json shape: 4 KB at config 2, 17 KB at
+    // config 5) -- a dozen dependent phases then cost LDS round trips instead of trips to the L2 (27.5 -> 23.9 us per call, profiles/r04aq: most of
+    // the kernel is the phases' own serial work and synchronisations);
+    // the global arrays of PlanDevArgs remain the fallback for schedules that do not fit.  `a` is this kernel's own copy of the arguments.
+    constexpr int POOL = 14336;                                    // 56 KB of the 64 KB a workgroup may declare statically
+    __shared__ __attribute__((aligned(16))) int32_t pool[POOL];
+    int used = 0;
+    {
+        const long long need = 2LL * a.nblk + 3LL * a.P + 1;
+        if (need <= POOL) {
+            a.lo = pool; a.hi = pool + a.nblk; a.first = pool + 2 * a.nblk; a.last = a.first + a.P; a.rcount = a.last + a.P;
+            used = (int)((need + 3) & ~3LL);
+        }
+    }
     __syncthreads();
     // ---- 1: per output block min/max of idx, range check, clamp
     for (int j = tid; j < a.nblk; j += nt) {
@@ -319,6 +333,11 @@ __global__ __launch_bounds__(1024) void k_plan_explicit(PlanDevArgs a) {
         nrow = 0;                                   // render nothing rather than part of the schedule
     }
     const int N = (int)nrow;
+    if (N > 0 && used + 6LL * N <= POOL) {                          // row-tasks (16 B) and sort keys (8 B) of the rows that exist, not of the capacity
+        a.rtask = pool + used;
+        a.keys = reinterpret_cast<unsigned long long*>(pool + used + 4 * N);     // (used and 4 N are multiples of 4 ints: 16-byte aligned)
+        used += 6 * N;
+    }
     // ---- 4: emit the row-tasks in time order
     if (N > 0)
         for (int r = tid; r < a.P; r += nt) {
@@ -353,6 +372,7 @@ __global__ __launch_bounds__(1024) void k_plan_explicit(PlanDevArgs a) {
     if (groups < 1 || (long long)N * a.C < 2LL * groups) groups = 1;
     const int cmax = crange[1], span = N > 0 ? cmax - crange[0] + 1 : 1;     // only the costs that occur get a bin
     const int nbins = groups * span;
+    if (used + nbins <= POOL) a.bins = pool + used;
     for (int i = tid; i < nbins; i += nt) a.bins[i] = 0;
     __syncthreads();
     const long long total = block_exclusive_scan(a.keys, N, sh);

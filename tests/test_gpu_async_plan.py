@@ -176,3 +176,24 @@ def test_two_threads_each_get_their_own_verdict():
         [t.join() for t in th]
     ops.async_status()
     assert not wrong, wrong[:5]
+
+
+def test_long_signal_uses_the_planner_global_scratch():
+    """the device planner keeps its scratch arrays in LDS when 2 * blocks + 3 * P + 1 <= 14 336 words (every BASELINE.json shape); a 33.5 M-sample
+    signal (8 193 blocks) takes the global-memory fallback -- same bits as the host-planned render there too"""
+    T, P, C, L = (8192 * 4096) + 777, 5, 1, 9000
+    ops, rng, dev, x, bank = _setup(T, P, C, L, 21)
+    cuts = np.sort(rng.integers(0, T + 1, P - 2))
+    seg = np.diff(np.concatenate([[0], cuts, [T]])).astype(np.int64)
+    idx = np.repeat(np.arange(P - 1), seg).astype(np.int64)
+    w = rng.random(T).astype(np.float32)
+    y_sync, y_async = _both(ops, x, bank, idx, w)
+    assert ops.async_status() == (0, 0)
+    assert torch.equal(y_sync, y_async)
+    del y_sync
+    sel = slice(T - 50000, T)
+    from oracle import moving as O
+    xs = x.cpu().numpy()
+    lo = sel.start - L
+    ref = O.convolve_moving_receiver(xs[lo:], bank.cpu().numpy(), idx[lo:], w[lo:])[:, L:]
+    assert O.rel_rms(y_async[:, sel].cpu().numpy(), ref) <= 1e-4
