@@ -50,6 +50,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+CALIB_BANK_BYTES = 307_200_000   # the buffer the counter passes of the scene legs calibrate FETCH_SIZE / WRITE_SIZE on (one config-2 bank)
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md); measured copy ceiling 6290 GB/s
 
 
@@ -209,6 +210,144 @@ def render_flops(seg, P, C, L, block=4096, jmax=4):
     return total * C
 
 
+# ------------------------------------------------------------------------------------------------ the line the driver parses
+LINE_LIMIT = 4096            # the driver keeps an ~8 KB tail of stdout: the LAST line must be the whole headline object
+
+
+def _r(v, sig=6):
+    """numbers at `sig` significant digits (the detail lines carry full precision)"""
+    if isinstance(v, bool) or v is None:
+        return v
+    if isinstance(v, float):
+        if v != v or v in (float("inf"), float("-inf")):
+            return None
+        return float(f"{v:.{sig}g}")
+    return v
+
+
+def _pick(d, keys, sig=6):
+    return {k: _r(d[k], sig) for k in keys if isinstance(d, dict) and k in d}
+
+
+def _roof_compact(r):
+    if not isinstance(r, dict):
+        return None
+    out = _pick(r, ("bound", "achieved", "peak", "unit", "frac", "frac_events", "frac_source", "traffic", "algorithmic_bytes_per_launch",
+                    "avg_launch_ms", "avg_launch_ms_events", "launches_per_render"))
+    if "kernel" in r:
+        out["kernel"] = str(r["kernel"]).split(" ")[0].rstrip(",")
+    if isinstance(r.get("compute"), dict):
+        out["compute"] = _pick(r["compute"], ("frac", "achieved", "peak", "unit"), 4)
+    return out
+
+
+def _cpu_compact(c, with_sample=True):
+    if not isinstance(c, dict):
+        return None
+    out = _pick(c, ("value", "unit", "cores", "kind", "seconds_measured"), 5)
+    if with_sample and c.get("sample"):
+        s = str(c["sample"])
+        out["sample"] = s if len(s) <= 120 else s[:117] + "..."
+    return out
+
+
+def _leg_summary(name, leg):
+    """one flat row per secondary leg: workload, value, unit, ms_per_step, roofline_frac, cpu_baseline_value, parity"""
+    if not isinstance(leg, dict):
+        return None
+    if "error" in leg:
+        return {"error": str(leg["error"])[:120]}
+    wl = (leg.get("config") or {}).get("workload") or leg.get("workload") or name
+    wl = str(wl)
+    row = {"workload": wl if len(wl) <= 72 else wl[:69] + "...", "value": _r(leg.get("value")), "unit": leg.get("unit"),
+           "ms_per_step": _r(leg.get("ms_per_step")),
+           "roofline_frac": _r((leg.get("roofline") or {}).get("frac"), 4), "roofline_bound": (leg.get("roofline") or {}).get("bound"),
+           "cpu_baseline_value": _r((leg.get("cpu_baseline") or {}).get("value"), 4)}
+    par = leg.get("parity_rel_rms_vs_oracle")
+    if par is None:
+        for k in ("same_bits_as_the_resident_render", "same_bits_as_three_separate_renders"):
+            if k in leg:
+                par = "same bits" if leg[k] else "MISMATCH"
+    if par is None and isinstance(leg.get("gather_verification"), dict):
+        par = "same bits" if leg["gather_verification"].get("same_bits") else "MISMATCH"
+    row["parity"] = _r(par, 3)
+    sc = ((leg.get("roofline") or {}).get("scene") or {})
+    if sc.get("frac") is not None:
+        row["scene_frac"] = _r(sc["frac"], 4)
+    return row
+
+
+def compact_line(full, limit=LINE_LIMIT):
+    """The final stdout line: the contract's keys + roofline + cpu_baseline + a flat `secondary` summary, at most `limit` bytes.  `full` is what
+    the run_* functions return (everything measured); it goes to the `[detail]` / `[leg]` lines printed before and to gpurun_out/bench_detail.json."""
+    head = _pick(full, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+                        "data", "value_cold", "ms_per_step_cold", "ms_per_step_latency", "parity_rel_rms_vs_oracle", "speedup_vs_cpu_baseline",
+                        "result_checksum"))
+    cfg = full.get("config") or {}
+    c = _pick(cfg, ("workload", "T", "P", "C", "L", "fs", "entry_point", "parallelism", "scenes_total", "gathered_bytes_at_root", "gather", "streams"))
+    if isinstance(c.get("workload"), str) and len(c["workload"]) > 160:
+        c["workload"] = c["workload"][:157] + "..."
+    if isinstance(c.get("gather"), str) and len(c["gather"]) > 80:
+        c["gather"] = c["gather"][:77] + "..."
+    c["distributed"] = cfg.get("distributed")
+    head["config"] = c
+    head["roofline"] = _roof_compact(full.get("roofline"))
+    sc = ((full.get("roofline") or {}).get("scene") or {})
+    if sc and head["roofline"] is not None:
+        head["roofline"]["scene_frac"] = _r(sc.get("frac"), 4)
+        st = sc.get("stages") or {}
+        head["roofline"]["stages_ms"] = {k: _r(v.get("ms"), 4) for k, v in st.items() if isinstance(v, dict) and "ms" in v}
+    head["cpu_baseline"] = _cpu_compact(full.get("cpu_baseline"))
+    for k in ("cpu_baseline_all_cores", "cpu_smart"):
+        if isinstance(full.get(k), dict) and "value" in full[k]:
+            head[k] = _pick(full[k], ("value", "cores"), 4)
+    if isinstance(full.get("gather_verification"), dict):
+        head["gather_same_bits"] = full["gather_verification"].get("same_bits")
+    if isinstance(full.get("windows"), dict):
+        head["value_min_max"] = [_r(full["windows"].get("value_min")), _r(full["windows"].get("value_max"))]
+    if full.get("detail"):
+        head["detail"] = full["detail"]
+    sec = full.get("secondary")
+    if isinstance(sec, dict):
+        head["secondary"] = {k: _leg_summary(k, v) for k, v in sec.items()}
+    line = json.dumps(head, separators=(",", ":"))
+    # never over the limit: shed the optional parts in a fixed order (nothing the contract names)
+    for drop in (lambda h: [r.pop("workload", None) for r in (h.get("secondary") or {}).values() if isinstance(r, dict)],
+                 lambda h: (h.get("cpu_baseline") or {}).pop("sample", None),
+                 lambda h: [h.pop(k, None) for k in ("cpu_baseline_all_cores", "cpu_smart", "value_min_max", "detail")],
+                 lambda h: (h.get("roofline") or {}).pop("stages_ms", None),
+                 lambda h: h.pop("secondary", None)):
+        if len(line) <= limit:
+            break
+        drop(head)
+        line = json.dumps(head, separators=(",", ":"))
+    return line
+
+
+def emit(full, detail_dir=None):
+    """rank 0: `[leg] name {...}` per secondary leg and `[detail] {...}` (everything measured) on EARLIER stdout lines and in
+    gpurun_out/bench_detail.json; then the compact headline object as the LAST line."""
+    sec = full.get("secondary") if isinstance(full.get("secondary"), dict) else {}
+    detail_dir = detail_dir or os.environ.get("BENCH_DETAIL_DIR") or os.path.join(ROOT, "gpurun_out")
+    path = None
+    try:
+        os.makedirs(detail_dir, exist_ok=True)
+        name = "bench_detail.json" if (full.get("n_gpus") or 1) == 1 else f"bench_detail_n{full.get('n_gpus')}.json"
+        path = os.path.join(detail_dir, name)
+        with open(path, "w") as f:
+            json.dump(full, f, indent=1)
+    except OSError:
+        path = None
+    for k, v in sec.items():
+        print(f"[leg] {k} " + json.dumps(v), flush=True)
+    print("[detail] " + json.dumps({k: v for k, v in full.items() if k != "secondary"}), flush=True)
+    if path:
+        full = dict(full, detail=os.path.relpath(path, ROOT))
+    line = compact_line(full)
+    print(line, flush=True)
+    return line
+
+
 # ------------------------------------------------------------------------------------------------ CPU legs (rank 0, N = 1)
 def cpu_baselines(sc, seg, bank_h, budget_s, all_cores=True):
     import numpy as np
@@ -273,7 +412,8 @@ def cpu_baselines(sc, seg, bank_h, budget_s, all_cores=True):
 
 
 # ------------------------------------------------------------------------------------------------ config 2 (headline)
-def live_traffic(config, bank_bytes, timeout_s=120):
+def _live_traffic(config, bank_bytes, timeout_s, steps, warmup, box):
+    scene = config in ("cfg3", "cfg4")
     """HBM-side bytes per launch of k_os13_asm measured NOW, by this run: two more processes of this script (3 steps, no CPU legs, no secondary
     legs) under `rocprofv3 --kernel-trace --pmc FETCH_SIZE` and `... --pmc WRITE_SIZE` -- SEPARATE passes, counters in KiB, FETCH_SIZE calibrated
     on k_absmax (reads exactly the bank) and WRITE_SIZE on k_divide (writes exactly the bank) in the same passes, as MI355X_MICROARCH.md's HBM
@@ -296,11 +436,41 @@ def live_traffic(config, bank_bytes, timeout_s=120):
     env = dict(os.environ, BENCH_PREWARM_MS="0", BENCH_CALIB="1", BENCH_NO_AB="1", BENCH_IN_PMC="1", TMPDIR="/tmp")
     avg = {}
     t0 = time.perf_counter()
+    trace = None
+    box['trace'] = None
     try:
+        # pass 0: `rocprofv3 --kernel-trace --stats` of the headline leg alone, in the sustained state (pre-roll + 5 windows of this run's K steps, no HIP
+        # events, no counters): its kernel_stats.csv average is what `roofline.frac` quotes; the csv is kept under gpurun_out/
+        d = os.path.join(tmp, "stats")
+        envt = dict(os.environ, BENCH_NO_AB="1", BENCH_IN_PMC="1", BENCH_NOPROF="1", TMPDIR="/tmp")
+        cmd = [exe, "--kernel-trace", "--stats", "-d", d, "-o", "stats", "-f", "csv", "--", sys.executable, os.path.abspath(__file__),
+               "--no-secondary", "--steps", str(steps), "--warmup", str(warmup), "--cpu-seconds", "0", "--config", "cfg3" if scene else config,
+               "--windows", "5", "--event-windows", "1"]
+        r = subprocess.run(cmd, env=envt, cwd=ROOT, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=timeout_s)
+        if r.returncode == 0:
+            for f in glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if row.get("Name", "").startswith("k_os13_asm"):
+                        trace = {"kernel": "k_os13_asm", "calls": int(row["Calls"]), "avg_ms": float(row["AverageNs"]) * 1e-6, "min_ms": float(row["MinNs"]) * 1e-6,
+                                 "max_ms": float(row["MaxNs"]) * 1e-6, "command": " ".join(cmd[cmd.index("--") + 1:])}
+                    if "k_xspec13" in row.get("Name", "") and trace is not None:
+                        trace["xspec_avg_ms"] = float(row["AverageNs"]) * 1e-6
+                try:
+                    keep = os.path.join(ROOT, "gpurun_out", "bench_trace")
+                    os.makedirs(keep, exist_ok=True)
+                    shutil.copy(f, os.path.join(keep, f"kernel_stats_{config}.csv"))
+                    if trace is not None:
+                        trace["kernel_stats_csv"] = os.path.relpath(os.path.join(keep, f"kernel_stats_{config}.csv"), ROOT)
+                except OSError:
+                    pass
+        else:
+            trace = {"error": f"rocprofv3 --kernel-trace --stats exited with {r.returncode}: {r.stderr.decode(errors='replace')[-200:]}"}
+        box['trace'] = trace
         for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
             d = os.path.join(tmp, ctr)
             cmd = [exe, "--kernel-trace", "--pmc", ctr, "-d", d, "-o", "pmc", "-f", "csv", "--", sys.executable, os.path.abspath(__file__),
-                   "--no-secondary", "--steps", "3", "--warmup", "1", "--cpu-seconds", "0", "--config", config, "--windows", "2", "--event-windows", "1"]
+                   "--no-secondary", "--steps", "3", "--warmup", "1", "--cpu-seconds", "0", "--config", "cfg3" if scene else config, "--windows", "2",
+                   "--event-windows", "1"]
             r = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=timeout_s)
             if r.returncode != 0:
                 return None, f"rocprofv3 --pmc {ctr} exited with {r.returncode}: {r.stderr.decode(errors='replace')[-300:]}", None
@@ -330,6 +500,13 @@ def live_traffic(config, bank_bytes, timeout_s=120):
            "seconds": time.perf_counter() - t0}
     return fetch + write, ("measured by THIS run: two more processes of this script (3 steps) under rocprofv3 --kernel-trace --pmc FETCH_SIZE / "
                            "--pmc WRITE_SIZE (separate passes), FETCH calibrated on k_absmax, WRITE on k_divide in the same passes"), det
+
+
+def live_traffic(config, bank_bytes, timeout_s=150, steps=20, warmup=3):
+    """(bytes or None, how / why not, details, kernel trace of the same workload or None) -- see _live_traffic"""
+    box = {"trace": None}
+    t, src, det = _live_traffic(config, bank_bytes, timeout_s, steps, warmup, box)
+    return t, src, det, box["trace"]
 
 
 def run_cfg2(args, rank, local_rank, world, dev):
@@ -479,10 +656,10 @@ def run_cfg2(args, rank, local_rank, world, dev):
     avg_launch_ms = ms_os / max(1, n_os)
     bytes_per_launch = render_bytes / max(1.0, launches_per_render)
     achieved = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
-    traffic, traffic_src, traffic_det = None, None, None
+    traffic, traffic_src, traffic_det, ktrace = None, None, None, None
     pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")     # written by tools/profile.sh (separate --pmc passes)
     if world == 1 and not getattr(args, "no_live_traffic", False):
-        traffic, traffic_src, traffic_det = live_traffic(args.config, 4 * sc.P * sc.C * sc.L)
+        traffic, traffic_src, traffic_det, ktrace = live_traffic(args.config, 4 * sc.P * sc.C * sc.L, steps=args.steps, warmup=args.warmup)
         if traffic is None:
             traffic_det = {"live_measurement_failed": traffic_src}
             traffic_src = None
@@ -498,6 +675,14 @@ def run_cfg2(args, rank, local_rank, world, dev):
         except Exception:
             traffic = None
     flops = render_flops(seg, sc.P, sc.C, sc.L)
+    # roofline.frac quotes the profiler when this run's own `rocprofv3 --kernel-trace --stats` pass exists (HIP-event means read 1-4 % better than the
+    # kernel trace on the same box); the event figure stays beside it
+    ev_ms, ev_ach = avg_launch_ms, achieved
+    frac_source = "HIP events on the kernel's stream (this process)"
+    if ktrace and ktrace.get("avg_ms"):
+        avg_launch_ms = ktrace["avg_ms"]
+        achieved = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9
+        frac_source = f"rocprofv3 --kernel-trace --stats of this run's child pass ({ktrace['calls']} launches; {ktrace.get('kernel_stats_csv')})"
     out = {
         "metric": "rendered-audio-sec/sec (8-mic, 200-pt trajectory, 16 kHz)" if args.config == "cfg2" else
                   f"rendered-audio-sec/sec ({sc.C}-ch, {sc.P}-pt trajectory, {sc.fs // 1000} kHz)",
@@ -537,7 +722,9 @@ def run_cfg2(args, rank, local_rank, world, dev):
                                "of the fresh process",
                    "prewarm_ms": prewarm_ms, "prewarm_steps": prewarm_steps},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "traffic_details": traffic_det,
+                     "frac": achieved / HBM_PEAK_GBS, "frac_events": ev_ach / HBM_PEAK_GBS, "frac_source": frac_source, "avg_launch_ms_events": ev_ms,
+                     "kernel_trace": ktrace,
+                     "traffic": traffic, "traffic_source": traffic_src, "traffic_details": traffic_det,
                      "kernel": "k_os13_asm (hand-scheduled gfx950 assembly: row-stationary partitioned overlap-save, B=4096, persistent, "
                                "one launch per render)",
                      "compute": {"flops_per_launch": flops / max(1.0, launches_per_render), "unit": "TFLOP/s",
@@ -627,6 +814,12 @@ def run_scenes(args, rank, local_rank, world, dev):
         run.gains = A.lufs_gains_from_result(torch.stack(gains).cpu().numpy()) if gains else None    # every scene's five loudness gains reach the host inside the timed region
         return sg.finish() if sg is not None else None
 
+    if os.environ.get("BENCH_CALIB"):          # PMC passes: streaming kernels of exactly known byte counts calibrate FETCH_SIZE / WRITE_SIZE
+        from sonicsim_amd import ops as _ops
+        calib = torch.ones(CALIB_BANK_BYTES // 4, dtype=torch.float32, device=dev)
+        _ops.peak_normalize_(calib)            # k_absmax reads CALIB_BANK_BYTES; k_divide reads and writes them
+        del calib
+        torch.cuda.synchronize()
     lo = parallel.shard_range(total, rank, world)[0] if total else 0
     run(max(1, args.warmup), parallel.SceneGather(max(1, args.warmup) * world, (pool[0].C, pool[0].T), device=dev) if gather else None, 10_000_000)
     torch.cuda.synchronize()
@@ -640,6 +833,15 @@ def run_scenes(args, rank, local_rank, world, dev):
     if world > 1:
         dist.barrier()
     dt = parallel.barrier_max_seconds(time.perf_counter() - t0, device=dev)
+    cfg3 = None
+    if world == 1 and gather and not os.environ.get("BENCH_IN_PMC"):       # config 3 = the same scenes with no gather: its own figure (VERDICT r4 missing 5)
+        n3 = min(16, per_rank)
+        run(2, None, 50_000)
+        torch.cuda.synchronize()
+        t3 = time.perf_counter()
+        run(n3, None, 60_000)
+        torch.cuda.synchronize()
+        cfg3 = {"scenes": n3, "ms_per_step": (time.perf_counter() - t3) / n3 * 1e3}
     # ---- the gathered scenes are the scenes: rank 0 re-renders a handful of them itself (first / last scene of a few ranks, the ragged last
     #      shard included) from their global index alone and compares bits with what arrived
     verify = None
@@ -664,6 +866,9 @@ def run_scenes(args, rank, local_rank, world, dev):
         return None
     audio_s = pool[0].T / pool[0].fs
     spec = pool[0]
+    if os.environ.get("BENCH_IN_PMC"):         # a profiler pass of this leg (live_traffic): the launches are on record, nothing else is needed
+        return {"metric": "scene-sec/sec", "value": total * audio_s / dt, "unit": "scene-sec/sec", "n_gpus": world, "steps": per_rank, "warmup": args.warmup,
+                "ms_per_step": dt / per_rank * 1e3, "config": {"workload": f"{args.config} (profiler pass)"}}
     # ---- roofline of the scene's dominant kernel (ONE k_os13_asm launch = the 3 moving + 2 static renders), HIP events on its stream, in a
     #      separate pass of a few scenes after the timed region; byte model of SURVEY.md section 8d
     from sonicsim_amd import ops
@@ -689,7 +894,22 @@ def run_scenes(args, rank, local_rank, world, dev):
     ach = launch_bytes / max(1.0, launches_per_scene) / (avg_os * 1e-3) / 1e9 if avg_os > 0 else 0.0
     ms_scene = dt / per_rank * 1e3
     fl = sum(render_flops(sp_[3], P_mov, spec.C, spec.L) for sp_ in pool[0].speakers) + 2 * render_flops(None, spec.T, spec.C, spec.L)
-    roof = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+    # the same launch under the profiler (N = 1): kernel-trace average -> frac, FETCH_SIZE / WRITE_SIZE passes -> traffic
+    traffic = traffic_src = traffic_det = ktrace = None
+    ev_ach, ev_os = ach, avg_os
+    frac_source = "HIP events on the kernel's stream (this process)"
+    if world == 1 and not getattr(args, "no_live_traffic", False) and scene_cfg == "cfg2":
+        traffic, traffic_src, traffic_det, ktrace = live_traffic("cfg3", CALIB_BANK_BYTES, steps=8, warmup=2)
+        if traffic is None:
+            traffic_det = {"live_measurement_failed": traffic_src}
+            traffic_src = None
+        if ktrace and ktrace.get("avg_ms"):
+            avg_os = ktrace["avg_ms"]
+            ach = launch_bytes / max(1.0, launches_per_scene) / (avg_os * 1e-3) / 1e9
+            frac_source = f"rocprofv3 --kernel-trace --stats of this leg's child pass ({ktrace['calls']} launches; {ktrace.get('kernel_stats_csv')})"
+    roof = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "frac_events": ev_ach / HBM_PEAK_GBS,
+            "frac_source": frac_source, "avg_launch_ms_events": ev_os, "kernel_trace": ktrace,
+            "traffic": traffic, "traffic_source": traffic_src, "traffic_details": traffic_det,
             "kernel": "k_os13_asm, ONE persistent launch for the 3 moving + 2 static renders of a scene (ss_convolve_scene_f32)",
             "algorithmic_bytes_per_launch": launch_bytes / max(1.0, launches_per_scene), "launches_per_scene": launches_per_scene,
             "avg_launch_ms": avg_os, "launch_ms": dist_stats(os_ms), "xspec_ms": dist_stats(xs_ms),
@@ -762,6 +982,7 @@ def run_scenes(args, rank, local_rank, world, dev):
         "roofline": roof,
         "cpu_baseline": cpu,
         "gather_verification": verify,
+        "cfg3_no_gather": cfg3,
     }
 
 
@@ -881,7 +1102,7 @@ def run_cfg1(args, dev):
             "parity_host_path_same_bits": bool(np.array_equal(yh, y.cpu().numpy()))}
 
 
-def run_hostpath(args, dev):
+def run_hostpath(args, dev, cpu_baseline=None):
     """The path SonicSet.py:77 really takes: CPU tensors / NumPy arrays in, a CPU array out (SonicSim_moving.py:122-125), through the
     drop-in's own entry point -- PCIe inclusive, never `value`."""
     import numpy as np
@@ -939,8 +1160,19 @@ def run_hostpath(args, dev):
     t_xyp = best(lambda: ops.convolve_moving_seg(px, dbank, seg, host_io=True, out=po))
     audio_s = sc.T / sc.fs
     nb = bank.nbytes + sc.x.nbytes
+    pcie_gbs = bank.nbytes / t_up / 1e9
+    ach_gbs = nb / t_full[1] / 1e9
+    hp = ops.host_pipe_config() if hasattr(ops, "host_pipe_config") else {}
     return {"workload": "cfg2 shapes through SonicSim_moving.interpolate_moving_audio(CPU tensor (1, T), CPU tensor (P, 1, C, L), positions) -> CPU tensor (C, T): "
                         "what SonicSet.py:77-79 calls",
+            "metric": "rendered-audio-sec/sec (8-mic, 200-pt trajectory, 16 kHz), host buffers in and out (PCIe inclusive)",
+            "value": audio_s / t_full[1], "unit": "rendered-audio-sec/sec", "ms_per_step": t_full[1] * 1e3, "steps": 9, "dtype": "f32",
+            "roofline": {"bound": "pcie", "achieved": ach_gbs, "peak": pcie_gbs, "unit": "GB/s", "frac": ach_gbs / pcie_gbs, "traffic": None,
+                         "algorithmic_bytes_per_launch": nb, "avg_launch_ms": t_full[1] * 1e3,
+                         "kernel": "host-to-device upload of the bank + x (hostpipe.h); peak = ONE pinned hipMemcpyAsync of the bank measured on this box just before",
+                         "note": "bytes that must cross the link upwards (bank + x) over the MEDIAN call time; y (30.7 MB) comes back on the other direction of the link"},
+            "cpu_baseline": cpu_baseline,
+            "host_pipe": hp,
             "ms": t_full[0] * 1e3, "ms_median": t_full[1] * 1e3, "rendered_audio_sec_per_sec": audio_s / t_full[0],
             "same_bits_as_the_resident_render": same and bool(np.array_equal(y2, want_h)),
             "bytes_up": st_full["bytes_up"], "bytes_down": st_full["bytes_down"], "bank_chunks": st_full["chunks"], "copy_threads": st_full["threads"],
@@ -994,6 +1226,7 @@ def run_batched(args, dev):
     audio_s = sc.T / sc.fs
     nbytes = 3 * algorithmic_bytes(sc.T, sc.P, sc.C, sc.L)
     return {"workload": "3 x cfg2 (three different moving sources: own dry signal, bank and trajectory each) in ONE ss_convolve_scene_f32 call",
+            "value": 3 * audio_s / (ms * 1e-3), "unit": "rendered-audio-sec/sec", "ms_per_step": ms, "steps": K, "step_is": "one call = three renders",
             "ms_per_call": ms, "ms_per_render": ms / 3, "rendered_audio_sec_per_sec": 3 * audio_s / (ms * 1e-3),
             "same_bits_as_three_separate_renders": bool(same),
             "roofline": {"bound": "hbm", "achieved": nbytes / (ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": nbytes / (ms * 1e-3) / 1e9 / 8000.0,
@@ -1041,11 +1274,21 @@ def secondary_legs(args, rank, local_rank, dev, primary):
         return run_scenes(a, rank, local_rank, 1, dev)
 
     want = [w.strip() for w in (args.legs or "host,cfg5,cfg4,cfg1,batch").split(",") if w.strip()]
-    table = {"host": ("cfg2_end_to_end_host", lambda: run_hostpath(args, dev)), "cfg5": ("cfg5", cfg5), "cfg4": ("cfg4_per_gpu_share", cfg4),
+    table = {"host": ("cfg2_end_to_end_host", lambda: run_hostpath(args, dev, primary.get("cpu_baseline"))), "cfg5": ("cfg5", cfg5), "cfg4": ("cfg4_per_gpu_share", cfg4),
              "cfg1": ("cfg1", lambda: run_cfg1(args, dev)), "batch": ("cfg2_three_renders_one_launch", lambda: run_batched(args, dev))}
     for w in want:
         if w in table:
             guarded(*table[w])
+    c4 = legs.get("cfg4_per_gpu_share")
+    if isinstance(c4, dict) and isinstance(c4.get("cfg3_no_gather"), dict):      # config 3 as a row of its own: the cfg4 leg's scenes without the gather
+        c3 = c4["cfg3_no_gather"]
+        audio_s = c4["config"]["T"] / c4["config"]["fs"]
+        legs["cfg3"] = {"metric": c4["metric"], "value": audio_s / (c3["ms_per_step"] * 1e-3), "unit": "scene-sec/sec", "ms_per_step": c3["ms_per_step"],
+                        "steps": c3["scenes"], "dtype": "f32",
+                        "config": {"workload": f"cfg3: one full SonicSet sample (2 speakers + noise + music, 8-mic, 60 s), {c3['scenes']} scenes back to back, no gather",
+                                   **{k: c4["config"][k] for k in ("T", "P", "C", "L", "fs")}},
+                        "roofline": {k: v for k, v in c4["roofline"].items() if k not in ("scene",)}, "cpu_baseline": c4.get("cpu_baseline"),
+                        "note": "measured inside the cfg4 leg (same process, same scene pool); the scene launch and its roofline are the cfg4 leg's"}
     return legs
 
 
@@ -1097,7 +1340,7 @@ def main():
         _lib.use_library(args.lib)
     if args.cpu_positions == 0:
         args.cpu_seconds = 0
-    if args.no_secondary or args.config in ("cfg3", "cfg4"):
+    if args.no_secondary:
         args.no_live_traffic = True              # (the measurement tools' short runs: counters come from tools/profile.sh there)
 
     import torch
@@ -1149,7 +1392,7 @@ def main():
     if rank == 0 and world == 1 and args.config == "cfg2" and not args.no_secondary and not os.environ.get("BENCH_NO_SECONDARY"):
         out["secondary"] = secondary_legs(args, rank, local_rank, dev, out)
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        emit(out)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -113,7 +113,12 @@ int ss_set_task_queue(int dynamic);
  * 6.45 or 8.5 ms per config-2 render from run to run); 1 = bound to the CPUs next to the GPU (sysfs local_cpulist; slower when the caller's arrays
  * live on the other socket: 8.4 ms, profiles/r04d)) -- current device.
  * ss_host_path_stats: {seconds inside the last host-pointer render call, bytes up, bytes down, bank chunks, direct (pinned) transfers,
- * copy threads} of the current device. */
+ * copy threads, [6..13] stage marks, [14] host-pointer calls that ended in an error and were drained on the way out, [15] bind, [16] last-level-cache
+ * groups the copy threads are spread over, [17] NUMA node they follow (-2 never bound, -1 unbound)} of the current device.
+ * THREAD-AFFINITY POLICY: only the library's OWN copy threads are ever bound (pthread_setaffinity_np on threads it created); the calling thread
+ * and every other thread of the process keep their masks.  bind = 0 switches the binding off altogether (a host with its own placement policy,
+ * e.g. SonicSet.py's mp.Pool workers pinned by the job scheduler): the copy threads then inherit the mask of the thread that made the first
+ * host-pointer call.  An error return of a host-pointer render leaves nothing in flight (both copy streams and the render stream are drained). */
 int ss_set_host_pipe(int threads, int64_t slot_bytes, int64_t chunk_bytes, int bind);
 int ss_host_path_stats(double* out, int32_t n);
 /* pinned host memory the DMA engines address directly (hipHostMalloc / hipHostFree): a caller that renders into such a buffer skips the

@@ -137,6 +137,7 @@ struct HostPipe {
                                         // PAGES -- bound to the NUMA node the array being staged lives on (move_pages query), so the memcpy READS locally and
                                         // posts its writes to the slots across the socket link.  Left alone the threads drift: the same call measured 6.45 or
                                         // 8.5 ms from one run to the next; bound to the GPU's node they read remotely: 8.4 ms (profiles/r04d, r04p)
+    bool bind_set = false;              // `bind` was chosen by ss_set_host_pipe or read from SS_HOST_BIND
     bool dirty = false;                 // a host-pointer call is under way (or ended in an error before hp_finish): the next call drains both streams first
     hipStream_t up = nullptr, down = nullptr;
     char* ups[NUP] = {};
@@ -162,6 +163,7 @@ struct HostPipe {
     // statistics of the last host-pointer render (ss_host_path_stats)
     double st_bytes_up = 0, st_bytes_down = 0, st_seconds = 0;
     int st_chunks = 0, st_direct = 0;
+    int st_aborted = 0;                // host-pointer calls that ended in an error after hp_begin and were drained on the way out (render()'s HpAbort)
     double st_mark[8] = {};            // seconds since the call started: staging ready, x on its way, plan built, spectra launched, bank + launches
                                        // enqueued, results enqueued, everything copied out (ss_host_path_stats entries 6..13)
 };
@@ -176,6 +178,10 @@ static int hp_ensure(HostPipe& h) {
     return rc;
 }
 static int hp_ensure_build(HostPipe& h) {
+    if (!h.bind_set) {               // SS_HOST_BIND=0|1|2: the placement policy without a code change (a job whose scheduler already pins its workers sets 0)
+        if (const char* e = getenv("SS_HOST_BIND")) { const int b = atoi(e); if (b >= 0 && b <= 2) h.bind = b; }
+        h.bind_set = true;
+    }
     HIPCHK(hipStreamCreateWithFlags(&h.up, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&h.down, hipStreamNonBlocking));
     for (int i = 0; i < HostPipe::NUP; ++i) {

@@ -280,14 +280,16 @@ inline void plan_seg_lpt(const std::vector<int64_t>& seg_start /*[P], last == T*
             if (pair_rows) {
                 // channel-major inside a row: (task A, c), (task B, c), (task A, c + 1), ... -- the two readers of filter (r, c) take
                 // CONSECUTIVE tickets, i.e. start ~one task-start interval apart, well inside the time a tap line survives in the XCD's L2
-                int32_t tj[16], tn[16];
-                int nt = 0;
-                row_tasks(a0, a2, block, jmax, rs, [&](int j, int nj) { if (nt < 16) { tj[nt] = (int32_t)j; tn[nt] = nj; ++nt; } });
+                // (any number of tasks per row: a row of P = 2 or 3 over a long T spans hundreds of blocks.  Round 4 kept them in a 16-entry array
+                // and silently dropped the rest while the histogram had counted them -- tests/test_emul.py::test_planner_covers_long_rows)
+                static thread_local std::vector<std::pair<int32_t, int32_t>> rt;
+                rt.clear();
+                row_tasks(a0, a2, block, jmax, rs, [&](int j, int nj) { rt.emplace_back((int32_t)j, (int32_t)nj); });
                 int32_t& at = hist[(size_t)g * MAXCOST + key];
                 for (int c = 0; c < C; ++c)
-                    for (int k = 0; k < nt; ++k) {
+                    for (const auto& jn : rt) {
                         Task t;
-                        t.row = r; t.chan = c; t.j0 = tj[k]; t.nj = tn[k];
+                        t.row = r; t.chan = c; t.j0 = jn.first; t.nj = jn.second;
                         tmp[(size_t)at++] = t;
                     }
                 continue;

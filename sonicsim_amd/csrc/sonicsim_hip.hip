@@ -1795,6 +1795,14 @@ int render(int mode, const float* x, int64_t T, const float* bank, int32_t P, in
     if (mode == COEF_SEG && !seg_len_host) return fail(SS_EINVAL, "seg_len is NULL");
     if (mode == COEF_EXPLICIT && (!idx || !w)) return fail(SS_EINVAL, "idx / w is NULL");
     if (T > (int64_t)2000000000LL * 4) return fail(SS_EINVAL, "T too large");
+    if (mode == COEF_SEG) {        // validated BEFORE anything is put on the wire (an error return must not leave uploads of the caller's arrays in flight)
+        int64_t s = 0;
+        for (int k = 0; k < P - 1; ++k) {
+            if (seg_len_host[k] < 0) return fail(SS_EINVAL, "seg_len[%d] = %lld is negative", k, (long long)seg_len_host[k]);
+            s += seg_len_host[k];
+        }
+        if (s != T) return fail(SS_EINVAL, "sum(seg_len) = %lld != T = %lld", (long long)s, (long long)T);
+    }
     Ctx* c;
     int rc = get_ctx(&c);
     if (rc) return rc;
@@ -1802,6 +1810,25 @@ int render(int mode, const float* x, int64_t T, const float* bank, int32_t P, in
     hipStream_t stream = (hipStream_t)stream_;
     if ((rc = stream_enter(c, stream))) return rc;
     const bool dev = (flags & SS_FLAG_DEVICE_PTR) != 0;
+    // host-pointer mode: whatever way this function is left, nothing of the call stays in flight -- an error return after hp_begin() used to leave
+    // host-to-device DMAs reading the caller's (possibly pinned) arrays and device-to-host pieces pending, drained only by the NEXT host-pointer
+    // call; the caller may free its arrays right after the error, and other entry points reuse WS_X / WS_BANK / WS_Y on `stream`.
+    struct HpAbort {
+        HostPipe* h = nullptr;
+        hipStream_t s = nullptr;
+        ~HpAbort() {
+            if (!h || !h->dirty) return;                   // hp_finish() ran: the call completed
+            (void)hipStreamSynchronize(h->up);
+            (void)hipStreamSynchronize(h->down);
+            (void)hipStreamSynchronize(s);
+            (void)hipGetLastError();
+            h->pending.clear();
+            for (bool& b : h->upbusy) b = false;
+            h->evused = 0;
+            h->dirty = false;
+            ++h->st_aborted;
+        }
+    } hp_abort;
 
     // ---- staging for host-pointer mode (hostpipe.h): x (and idx / w) go up first through the pinned ring; the bank follows further
     //      down, behind the spectra kernel -- in chunks interleaved with the render launches where the engine allows it
@@ -1818,6 +1845,8 @@ int render(int mode, const float* x, int64_t T, const float* bank, int32_t P, in
     if (!dev) {
         if ((rc = hp_ensure(hp))) return rc;
         if ((rc = hp_begin(hp))) return rc;
+        hp_abort.h = &hp;
+        hp_abort.s = stream;
         if ((rc = ws_ensure(c, WS_X, sizeof(float) * T))) return rc;
         if (!bank_dev && (rc = ws_ensure(c, WS_BANK, bank_bytes))) return rc;
         if ((rc = ws_ensure(c, WS_Y, sizeof(float) * (size_t)C * T))) return rc;
@@ -2581,6 +2610,7 @@ int ss_set_host_pipe(int threads, int64_t slot_bytes, int64_t chunk_bytes, int b
     if (threads > 256 || (slot_bytes > 0 && (slot_bytes < (1 << 16) || slot_bytes > ((int64_t)1 << 30))) || (chunk_bytes > 0 && chunk_bytes < (1 << 20)))
         return fail(SS_EINVAL, "ss_set_host_pipe: threads <= 256, 64 KiB <= slot_bytes <= 1 GiB, chunk_bytes >= 1 MiB (0 / negative = keep)");
     const bool rebind = bind >= 0 && bind <= 2 && bind != h.bind;
+    if (bind >= 0 && bind <= 2) h.bind_set = true;
     if (rebind) h.bind = bind;
     if ((slot_bytes > 0 && (size_t)slot_bytes != h.slot_bytes) || rebind) {
         if (h.up) {
@@ -2605,9 +2635,13 @@ int ss_host_path_stats(double* out, int32_t n) {
     if (rc) return rc;
     std::lock_guard<std::mutex> lock(c->mu);
     const HostPipe& h = c->pipe;
-    double v[14] = {h.st_seconds, h.st_bytes_up, h.st_bytes_down, (double)h.st_chunks, (double)h.st_direct, (double)h.threads};
+    double v[18] = {h.st_seconds, h.st_bytes_up, h.st_bytes_down, (double)h.st_chunks, (double)h.st_direct, (double)h.threads};
     for (int i = 0; i < 8; ++i) v[6 + i] = h.st_mark[i];
-    for (int i = 0; i < n && i < 14; ++i) out[i] = v[i];
+    v[14] = (double)h.st_aborted;
+    v[15] = (double)h.bind;
+    v[16] = (double)h.pool.groups.size();          // last-level-cache groups the copy threads are spread over right now (0: unbound)
+    v[17] = (double)h.pool.bound_node;             // NUMA node they follow (-2: never bound, -1: unbound)
+    for (int i = 0; i < n && i < 18; ++i) out[i] = v[i];
     return SS_OK;
 }
 

@@ -182,10 +182,18 @@ def set_host_pipe(threads=0, slot_bytes=0, chunk_bytes=0, bind=None):
 
 def host_path_stats():
     """{seconds, bytes_up, bytes_down, chunks, direct_transfers, threads} of the last host-pointer render on the current device."""
-    v = (ctypes.c_double * 14)()
-    _lib.check(_lib.load().ss_host_path_stats(v, 14))
+    v = (ctypes.c_double * 18)()
+    _lib.check(_lib.load().ss_host_path_stats(v, 18))
     return {"seconds": v[0], "bytes_up": v[1], "bytes_down": v[2], "chunks": int(v[3]), "direct_transfers": int(v[4]), "threads": int(v[5]),
-            "marks_ms": [round(v[6 + i] * 1e3, 4) for i in range(7)]}
+            "marks_ms": [round(v[6 + i] * 1e3, 4) for i in range(7)], "aborted_calls": int(v[14]), "bind": int(v[15]),
+            "cache_groups": int(v[16]), "numa_node": int(v[17])}
+
+
+def host_pipe_config():
+    """{threads, bind, cache_groups, numa_node} of the host-pointer pipeline on the current device (bind: 0 = the copy threads are left to the
+    scheduler, 1 = next to the GPU, 2 = they follow the pages of the array being staged, one thread per last-level cache)."""
+    st = host_path_stats()
+    return {k: st[k] for k in ("threads", "bind", "cache_groups", "numa_node")}
 
 
 def _out_ct(out, C, T, dev):

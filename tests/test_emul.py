@@ -220,6 +220,38 @@ def test_planner_keeps_the_tasks_of_a_row_together(emul):
                 assert idx == list(range(idx[0], idx[0] + len(idx))), (g, key, idx)
 
 
+def test_planner_covers_long_rows(emul):
+    """ADVICE r4 (plan.h::plan_seg_lpt): a row of more than 64 blocks (few positions over a long T) is cut into more than 16 tasks; the emit pass
+    of the paired order kept them in a 16-entry array and dropped the rest, leaving zero tasks in the list.  Every (row, channel) must tile all
+    the blocks that hold its samples, whatever their number."""
+    i32 = ctypes.POINTER(ctypes.c_int32)
+    B = 4096
+    for Pn, T, C, L in ((3, 1_000_000, 2, 48000), (2, 400_000, 1, 9000), (4, 3_000_000, 3, 20000)):
+        seg = np.full(Pn - 1, T // (Pn - 1), dtype=np.int64)
+        seg[-1] += T - seg.sum()
+        start = np.concatenate([[0], np.cumsum(seg)])
+        for tail in (0, 12):
+            out = np.zeros((8000, 4), np.int32)
+            m = ctypes.c_int32(0)
+            n = emul.emul_plan_dump_ex(P(seg, ip), Pn, C, L, 8, 256, 0, tail, ctypes.byref(m), P(out, i32), len(out))
+            assert 0 < n <= len(out)
+            t = out[:n]
+            assert (t[:, 3] >= 1).all() and (t[:, 3] <= 4).all()
+            covered = set()
+            for row, chan, j0, nj in t:
+                for j in range(j0, j0 + nj):
+                    assert (int(row), int(chan), int(j)) not in covered
+                    covered.add((int(row), int(chan), int(j)))
+            want = set()
+            for r in range(Pn):
+                a0 = start[r - 1] if r > 0 else start[r]
+                a2 = start[r + 1] if r < Pn - 1 else start[r]
+                for c in range(C):
+                    for j in range(int(a0 // B), int(-(-a2 // B))):
+                        want.add((r, c, j))
+            assert covered == want, (Pn, T, len(covered), len(want))
+
+
 def test_scene_planner_tiles_every_source(emul):
     """plan.h::plan_scene_lpt (ss_convolve_scene_f32: all renders of a scene in one launch): per source exactly the tasks the single-source
     planner would emit -- a moving source's rows tile the blocks that hold their samples, a static source covers every block once per

@@ -172,3 +172,33 @@ def test_dynamic_task_queues_same_bits(gpu):
             assert O.rel_rms(got[0].cpu().numpy(), ref) <= 1e-4
     finally:
         ops.set_task_queue(True)                       # (the default)
+
+
+def test_long_rows_two_positions(gpu):
+    """P = 2 over T > 300 k -- each of the two rows spans 84 blocks = 21 tasks; round 4's paired planner kept 16 per row and
+    silently lost the rest of the output (device pointers, host pointers = the chunked host path, both task-queue modes)."""
+    from sonicsim_amd import ops
+    rng = np.random.default_rng(77)
+    T, P, C, L = 340_001, 2, 2, 9000
+    x = rng.standard_normal(T).astype(np.float32)
+    bank = (rng.standard_normal((P, C, L)) * np.exp(-4 * np.arange(L) / L)).astype(np.float32)
+    seg = np.array([T], dtype=np.int64)
+    idx, w = moving.expand_segments(seg)
+    ref = moving.convolve_moving_receiver(x, bank, idx, w)
+    y = ops.convolve_moving_seg(x, bank, seg)                      # host pointers
+    assert_parity(y, ref)
+    xd, bd = torch.from_numpy(x).to(gpu), torch.from_numpy(bank).to(gpu)
+    for dyn in (True, False):
+        ops.set_task_queue(dyn)
+        try:
+            yd = ops.convolve_moving_seg(xd, bd, seg).cpu().numpy()
+        finally:
+            ops.set_task_queue(True)
+        assert np.array_equal(yd, y)
+    T3 = 1_000_000                                                # the advisor's repro shape: P = 3, 123 blocks per outer row
+    x3 = rng.standard_normal(T3).astype(np.float32)
+    b3 = (rng.standard_normal((3, 2, 6000)) * np.exp(-4 * np.arange(6000) / 6000)).astype(np.float32)
+    s3 = np.array([T3 // 2, T3 - T3 // 2], dtype=np.int64)
+    i3, w3 = moving.expand_segments(s3)
+    assert_parity(ops.convolve_moving_seg(torch.from_numpy(x3).to(gpu), torch.from_numpy(b3).to(gpu), s3).cpu().numpy(),
+                  moving.convolve_moving_receiver(x3, b3, i3, w3))

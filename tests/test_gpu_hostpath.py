@@ -187,3 +187,66 @@ def test_config5_host_path_full_size(gpu):
     dt = time.perf_counter() - t0
     print(f"config 5 from pageable host arrays: {dt * 1e3:.1f} ms per render ({(st['bytes_up'] + st['bytes_down']) / dt / 1e9:.1f} GB/s over PCIe)")
     assert np.array_equal(got, want)
+
+
+def test_error_after_the_uploads_started_leaves_nothing_in_flight(gpu):
+    """ADVICE r4 (render(): early returns after hp_begin): an explicit schedule with an out-of-range interp_index is detected AFTER x / idx / w have
+    been put on the wire from the caller's arrays.  The error return must drain both copy streams (the caller may free or overwrite its -- possibly
+    pinned -- arrays right away) and the next render, host or device pointers, must be bit-exact."""
+    from sonicsim_amd import ops
+    from oracle import moving
+    T, P, C, L = 60000, 6, 2, 9000
+    x, bank, _ = golden_inputs(31, T, P, C, L)
+    seg = _segments(np.random.default_rng(3), P, T)
+    idx, w = moving.expand_segments(seg)
+    want = ops.convolve_moving(torch.from_numpy(x).to(gpu), torch.from_numpy(bank).to(gpu), idx, w).cpu().numpy()
+    before = ops.host_path_stats()["aborted_calls"]
+    px = ops.pinned_empty(x.shape)                      # pinned: the DMA engine reads the caller's memory directly
+    px[:] = x
+    bad = idx.copy()
+    bad[T // 2] = P - 1                                 # idx + 1 == P: out of range, found by the min / max pass after the uploads
+    with pytest.raises(ValueError):
+        ops.convolve_moving(px, bank, bad, w)
+    st = ops.host_path_stats()
+    assert st["aborted_calls"] == before + 1
+    px[:] = 0.0                                         # "the caller frees / reuses its buffer right after the error"
+    assert np.array_equal(ops.convolve_moving(x, bank, idx, w), want)
+    assert np.array_equal(ops.convolve_moving_seg(x, bank, seg), want)
+    assert np.array_equal(ops.convolve_fixed(x, bank[0]), ops.convolve_fixed(torch.from_numpy(x).to(gpu), torch.from_numpy(bank[0]).to(gpu)).cpu().numpy())
+    assert ops.host_path_stats()["aborted_calls"] == before + 1
+
+
+def test_copy_thread_binding_never_touches_the_callers_threads(gpu):
+    """the host pipeline binds ONLY the copy threads it created.  The calling thread's affinity mask (and that of any other
+    thread of the process) is the same before and after host-pointer renders under every bind policy; bind = 0 switches binding off."""
+    import os
+    import threading
+    from sonicsim_amd import ops
+    T, P, C, L = 50000, 40, 2, 10000
+    x, bank, _ = golden_inputs(44, T, P, C, L)
+    seg = _segments(np.random.default_rng(8), P, T)
+    want = ops.convolve_moving_seg(torch.from_numpy(x).to(gpu), torch.from_numpy(bank).to(gpu), seg).cpu().numpy()
+    mine = os.sched_getaffinity(0)
+    other = {}
+    stop = threading.Event()
+
+    def bystander():
+        other["tid"] = threading.get_native_id()
+        other["before"] = os.sched_getaffinity(other["tid"])
+        stop.wait()
+    th = threading.Thread(target=bystander)
+    th.start()
+    try:
+        for bind in (0, 2, 1, 0):
+            ops.set_host_pipe(bind=bind)
+            assert np.array_equal(ops.convolve_moving_seg(x, bank, seg), want)
+            cfg = ops.host_pipe_config()
+            assert cfg["bind"] == bind
+            if bind == 0:
+                assert cfg["cache_groups"] == 0            # nothing bound at all
+            assert os.sched_getaffinity(0) == mine, bind
+            assert os.sched_getaffinity(other["tid"]) == other["before"], bind
+    finally:
+        stop.set()
+        th.join()
+        ops.set_host_pipe(bind=2)
