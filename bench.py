@@ -433,7 +433,7 @@ def _live_traffic(config, bank_bytes, timeout_s, steps, warmup, box):
         tmp = tempfile.mkdtemp(prefix="bench_pmc_", dir="/tmp")
     except OSError as e:
         return None, f"no scratch directory: {e}", None
-    env = dict(os.environ, BENCH_PREWARM_MS="0", BENCH_CALIB="1", BENCH_NO_AB="1", BENCH_IN_PMC="1", TMPDIR="/tmp")
+    env = dict(os.environ, BENCH_PREWARM_MS="0", BENCH_CALIB="1", BENCH_NO_AB="1", BENCH_IN_PMC="1", BENCH_SERIAL="1", TMPDIR="/tmp")
     avg = {}
     t0 = time.perf_counter()
     trace = None
@@ -442,7 +442,7 @@ def _live_traffic(config, bank_bytes, timeout_s, steps, warmup, box):
         # pass 0: `rocprofv3 --kernel-trace --stats` of the headline leg alone, in the sustained state (pre-roll + 5 windows of this run's K steps, no HIP
         # events, no counters): its kernel_stats.csv average is what `roofline.frac` quotes; the csv is kept under gpurun_out/
         d = os.path.join(tmp, "stats")
-        envt = dict(os.environ, BENCH_NO_AB="1", BENCH_IN_PMC="1", BENCH_NOPROF="1", TMPDIR="/tmp")
+        envt = dict(os.environ, BENCH_NO_AB="1", BENCH_IN_PMC="1", BENCH_NOPROF="1", BENCH_SERIAL="1", TMPDIR="/tmp")
         cmd = [exe, "--kernel-trace", "--stats", "-d", d, "-o", "stats", "-f", "csv", "--", sys.executable, os.path.abspath(__file__),
                "--no-secondary", "--steps", str(steps), "--warmup", str(warmup), "--cpu-seconds", "0", "--config", "cfg3" if scene else config,
                "--windows", "5", "--event-windows", "1"]
@@ -521,7 +521,13 @@ def run_cfg2(args, rank, local_rank, world, dev):
     bank, peak = ops.rir_bank_synth(sc.delay, sc.dgain, sc.L, sc.fs, sc.rt60, sc.bank_seed, device=dev, return_peak=True)   # K1 (row R)
     ops.divide_by_(bank, peak)                                                                        # row G, materialised
     x = torch.from_numpy(sc.x).to(dev)
-    scratch = torch.empty((sc.C, sc.T), dtype=torch.float32, device=dev)
+    scratch = [torch.empty((sc.C, sc.T), dtype=torch.float32, device=dev) for _ in range(2)]      # two renders may be in flight: one output each
+    # independent renders alternate over two streams (ops.RenderStreams: the library keeps a workspace lane per stream), so render i + 1's spectra
+    # launch runs on the compute units render i's persistent launch frees one by one at its end; --serial / BENCH_SERIAL=1: one stream (the
+    # profiler passes and the event windows, which time the render kernel ALONE, always run that way)
+    import contextlib
+    overlap = not (getattr(args, "serial", False) or os.environ.get("BENCH_SERIAL") == "1")
+    rstreams = ops.RenderStreams(dev, depth=2) if overlap else None
     if os.environ.get("BENCH_CALIB"):          # PMC passes (tools/profile.sh): streaming kernels of exactly known byte counts calibrate FETCH_SIZE / WRITE_SIZE
         calib = bank.clone()
         ops.peak_normalize_(calib)             # k_absmax reads 4PCL bytes; k_divide reads and writes 4PCL bytes
@@ -535,17 +541,20 @@ def run_cfg2(args, rank, local_rank, world, dev):
     def make_gather():
         return parallel.SceneGather(world * ngath, (sc.C, sc.T), device=dev) if ngath else None
 
-    def run_steps(k, sg=None):
+    def run_steps(k, sg=None, serial=False):
         """k renders; with a SceneGather every ge-th render lands in its slot and travels to rank 0 while the next renders run"""
         y = None
-        for i in range(k):
-            j = i // ge
-            out = scratch
-            if sg is not None and i % ge == ge - 1 and j < ngath:
-                out = sg.slot(j)
-            y = ops.convolve_moving_seg(x, bank, seg, out=out)          # rows I+V: O(P*C) plan on the host, 2 kernel launches (spectra, render)
-            if sg is not None and i % ge == ge - 1 and j < ngath:
-                sg.submit(j)
+        rs = None if serial else rstreams
+        with (rs if rs is not None else contextlib.nullcontext()):
+            for i in range(k):
+                j = i // ge
+                out = scratch[i % 2]
+                with (rs.next() if rs is not None else contextlib.nullcontext()):      # slot / render / submit of step i on ITS stream
+                    if sg is not None and i % ge == ge - 1 and j < ngath:
+                        out = sg.slot(j)
+                    y = ops.convolve_moving_seg(x, bank, seg, out=out)      # rows I+V: O(P*C) plan on the host, 2 kernel launches (spectra, render)
+                    if sg is not None and i % ge == ge - 1 and j < ngath:
+                        sg.submit(j)
         if sg is not None:
             sg.finish()
         return y
@@ -556,13 +565,13 @@ def run_cfg2(args, rank, local_rank, world, dev):
             run_steps(ge, parallel.SceneGather(world, (sc.C, sc.T), device=dev))
             torch.cuda.synchronize()
 
-    def timed(k):
+    def timed(k, serial=False):
         sg = make_gather()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        y = run_steps(k, sg)
+        y = run_steps(k, sg, serial)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -595,13 +604,14 @@ def run_cfg2(args, rank, local_rank, world, dev):
     windows, ev_windows = [], []
     y = None
 
-    def window(events):
-        run_steps(args.warmup)
+    def window(events, serial=False):
+        serial = serial or bool(events)          # the event windows time the render kernel alone: one stream
+        run_steps(args.warmup, None, serial)
         torch.cuda.synchronize()
         if events:
             ops.prof_enable(True, every=prof_every)
         c_before = tel.snap()
-        dtw, yy = timed(args.steps)
+        dtw, yy = timed(args.steps, serial)
         c_after = tel.snap()
         rec = {"dt": dtw, "clk_before": c_before, "clk_after": c_after, "os_ms": [], "xs_ms": [], "seen": 0}
         if events:
@@ -623,6 +633,11 @@ def run_cfg2(args, rank, local_rank, world, dev):
         rec, yy = window(ev)
         (ev_windows if ev else windows).append(rec)
         y = yy
+    serial_windows = []
+    if overlap:                                  # the one-stream step (= the latency of a single render: spectra launch + render launch) beside the throughput figure
+        for _ in range(3):
+            rec, _yy = window(False, serial=True)
+            serial_windows.append(rec["dt"] / args.steps * 1e3)
     if not ev_windows:
         ev_windows = [dict(windows[0])]
     if not windows:
@@ -699,6 +714,12 @@ def run_cfg2(args, rank, local_rank, world, dev):
         "data": "synthetic",
         "value_cold": world * args.steps * audio_s / dt_cold,
         "ms_per_step_cold": dt_cold / args.steps * 1e3,
+        "ms_per_step_latency": sorted(serial_windows)[len(serial_windows) // 2] if serial_windows else dt / args.steps * 1e3,
+        "streams": {"render_streams": 2 if overlap else 1,
+                    "how": ("independent renders alternate over two streams (ops.RenderStreams; one workspace lane per stream in the library): the next render's "
+                            "spectra launch fills the compute units the persistent launch frees at its end; ms_per_step_latency = the same K steps on ONE stream")
+                           if overlap else "one stream (--serial)",
+                    "ms_per_step_one_stream_windows": serial_windows, "workspace_lanes": ops.workspace_lanes()},
         "windows": {"count": nwin, "value_is": "median of the value windows (no HIP events inside them)",
                     "ms_per_step": [wdw["dt"] / args.steps * 1e3 for wdw in windows],
                     "value_min": world * args.steps * audio_s / max(wdw["dt"] for wdw in windows),
@@ -714,7 +735,7 @@ def run_cfg2(args, rank, local_rank, world, dev):
         "config": {"workload": f"{args.config}: single moving source, {sc.C}-mic, {audio_s:.0f} s @ {sc.fs} Hz, "
                                f"{sc.P} trajectory points, {sc.L}-tap RIRs (T={sc.T})",
                    "T": sc.T, "P": sc.P, "C": sc.C, "L": sc.L, "fs": sc.fs,
-                   "entry_point": "ss_convolve_moving_seg_f32", "parallelism": f"scene-sharded x{world}", "distributed": args.dist_info, "task_queue": "dynamic, one per XCD (the default; ss_set_task_queue)",
+                   "entry_point": "ss_convolve_moving_seg_f32", "streams": 2 if overlap else 1, "parallelism": f"scene-sharded x{world}", "distributed": args.dist_info, "task_queue": "dynamic, one per XCD (the default; ss_set_task_queue)",
                    "gather": f"every {ge}th render of every rank to rank 0, overlapped with the next renders" if do_gather else False,
                    "value_is": f"sustained: the MEDIAN of {nwin} windows, each = W warm-up steps + exactly K timed steps between barrier + "
                                "synchronize, after an untimed pre-roll (all windows are listed under `windows`; the HIP events behind `roofline` "
@@ -899,7 +920,7 @@ def run_scenes(args, rank, local_rank, world, dev):
     ev_ach, ev_os = ach, avg_os
     frac_source = "HIP events on the kernel's stream (this process)"
     if world == 1 and not getattr(args, "no_live_traffic", False) and scene_cfg == "cfg2":
-        traffic, traffic_src, traffic_det, ktrace = live_traffic("cfg3", CALIB_BANK_BYTES, steps=8, warmup=2)
+        traffic, traffic_src, traffic_det, ktrace = live_traffic("cfg3", CALIB_BANK_BYTES, steps=56, warmup=8)      # (sustained state: 64 scenes, like the leg itself)
         if traffic is None:
             traffic_det = {"live_measurement_failed": traffic_src}
             traffic_src = None
@@ -1325,6 +1346,7 @@ def main():
     ap.add_argument("--no-all-cores", action="store_true")
     ap.add_argument("--gather-every", type=int, default=5)
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--serial", action="store_true", help="one stream: no overlap between consecutive independent renders (the profiler passes run this way)")
     ap.add_argument("--windows", type=int, default=7, help="timed K-step windows of the sustained section (value = the median window)")
     ap.add_argument("--event-windows", type=int, default=None)
     ap.add_argument("--no-live-traffic", action="store_true", help="roofline.traffic from the committed profiles/pmc_summary.json instead of two rocprofv3 "

@@ -100,6 +100,14 @@ int ss_convolve_moving_checked_f32(const float* x, int64_t T, const float* rirs,
  * time.  Same output bits either way. */
 int ss_set_task_queue(int dynamic);
 
+/* ---- streams.  Every entry point is stream-ordered on the `stream` it is given and re-entrant per device.  The library's internal workspace
+ * (input spectra, staged plan, queue heads, reduction scratch) exists once per STREAM: up to four streams per device are live at once, each in
+ * its own workspace lane, so a caller that alternates two streams over independent renders (SonicSet.py:77-94 issues five per sample) gets render
+ * i + 1's spectra launch and first tickets under the draining tail of render i's persistent launch -- the step then costs the render kernel
+ * alone (0.182 -> 0.168 ms per config-2 render).  A fifth stream takes over the least recently used lane after synchronising
+ * that lane's stream.  ss_workspace_lanes: {lanes, lanes in use, lane switches so far, takeovers (each one a stream synchronisation)}. */
+int ss_workspace_lanes(int32_t* out, int32_t n);
+
 /* ---- host-pointer mode (flags without SS_FLAG_DEVICE_PTR): the path SonicSim_moving.py:122-125 really takes -- NumPy in, NumPy out.
  * The library moves the caller's arrays through a ring of pinned staging slots filled by a few host threads while the DMA engine drains
  * them (a single memcpy stream cannot keep the PCIe link busy), and for the implicit schedule on the assembly engine it cuts the bank into

@@ -1555,12 +1555,26 @@ struct Ctx {
     hipFunction_t fn13q = nullptr;
     bool mod13q_tried = false;
     int os_geom = 0;        // SS_OS_GEOM: 11 (B=2048, 256 thr) / 12 (B=4096, 512 thr, spectrum window); 0 = by filter length
-    void* ws[WS_COUNT] = {};
+    void* ws[WS_COUNT] = {};              // the ACTIVE lane's workspace (see Lane / stream_enter)
     size_t ws_cap[WS_COUNT] = {};
-    Pinned ring[4];
+    static constexpr int NRING = 8;
+    Pinned ring[NRING];
     int ring_next = 0;
-    hipStream_t last_stream = nullptr;
-    bool have_last = false;
+    // Workspace LANES (round 5): the workspace is stream-ordered, and rounds 1-4 serialised a stream switch against the previous stream.  A caller
+    // that alternates two streams -- independent renders, render i + 1's spectra launch and first tickets under render i's draining tail -- now gets
+    // one private workspace per stream: up to NLANE streams are live at once, a further one takes over the least recently used lane after
+    // synchronising that lane's stream.  ws[] / ws_cap[] above are the active lane's slots; WS_K1 (the bank generator's own lane) is shared.
+    static constexpr int NLANE = 4;
+    struct Lane {
+        void* ws[WS_COUNT] = {};
+        size_t cap[WS_COUNT] = {};
+        hipStream_t stream = nullptr;
+        bool used = false;
+        uint64_t tick = 0;
+    } lanes[NLANE];
+    int cur_lane = 0;
+    uint64_t lane_tick = 0;
+    int lane_switches = 0, lane_evictions = 0;
     size_t k1_batch_per = 0;              // slot words per bank of the batched generator's layout in WS_K1 (0: the single-bank layout)
     hipStream_t k1_stream = nullptr;      // the bank generator's own lane (it only touches WS_K1): see stream_enter_k1
     bool have_k1 = false;
@@ -1656,11 +1670,40 @@ int ws_ensure(Ctx* c, int slot, size_t bytes) {
     return SS_OK;
 }
 
-// stream switch: the workspace is stream-ordered, so serialise against the previous stream
+// stream switch: the workspace is stream-ordered -- every stream works in its own lane (Ctx::Lane), so two streams never share a buffer and a
+// switch costs a few pointer copies instead of a device synchronisation.  Only when more than NLANE streams are live is the least recently used
+// lane's stream synchronised and its buffers handed to the newcomer.
 int stream_enter(Ctx* c, hipStream_t s) {
-    if (c->have_last && c->last_stream != s) HIPCHK(hipStreamSynchronize(c->last_stream));
-    c->last_stream = s;
-    c->have_last = true;
+    Ctx::Lane& cur = c->lanes[c->cur_lane];
+    ++c->lane_tick;
+    if (cur.used && cur.stream == s) { cur.tick = c->lane_tick; return SS_OK; }
+    int pick = -1;
+    for (int i = 0; i < Ctx::NLANE; ++i) if (c->lanes[i].used && c->lanes[i].stream == s) pick = i;
+    if (pick < 0) for (int i = 0; i < Ctx::NLANE && pick < 0; ++i) if (!c->lanes[i].used) pick = i;
+    if (pick < 0) {                          // every lane belongs to another stream: take over the least recently used one
+        for (int i = 0; i < Ctx::NLANE; ++i) if (i != c->cur_lane && (pick < 0 || c->lanes[i].tick < c->lanes[pick].tick)) pick = i;
+        HIPCHK(hipStreamSynchronize(c->lanes[pick].stream));
+        ++c->lane_evictions;
+    }
+    if (pick != c->cur_lane) {
+        for (int i = 0; i < WS_COUNT; ++i) {
+            if (i == WS_K1) continue;        // the bank generator's slots are ordered by ITS stream (stream_enter_k1), whatever lane is active
+            cur.ws[i] = c->ws[i]; cur.cap[i] = c->ws_cap[i];
+            c->ws[i] = c->lanes[pick].ws[i]; c->ws_cap[i] = c->lanes[pick].cap[i];
+        }
+        c->cur_lane = pick;
+        ++c->lane_switches;
+    }
+    c->lanes[pick].used = true;
+    c->lanes[pick].stream = s;
+    c->lanes[pick].tick = c->lane_tick;
+    return SS_OK;
+}
+
+// host reads of state that any lane may have written (the device planner's status words): every OTHER live stream is drained first
+int sync_other_lanes(Ctx* c, hipStream_t s) {
+    for (int i = 0; i < Ctx::NLANE; ++i)
+        if (c->lanes[i].used && c->lanes[i].stream != s) HIPCHK(hipStreamSynchronize(c->lanes[i].stream));
     return SS_OK;
 }
 
@@ -1676,7 +1719,7 @@ int stream_enter_k1(Ctx* c, hipStream_t s) {
 
 int pinned_acquire(Ctx* c, size_t bytes, Pinned** out) {
     Pinned& p = c->ring[c->ring_next];
-    c->ring_next = (c->ring_next + 1) & 3;
+    c->ring_next = (c->ring_next + 1) % Ctx::NRING;
     if (p.pending) {
         HIPCHK(hipEventSynchronize(p.ev));
         p.pending = false;
@@ -2458,6 +2501,9 @@ int ss_shutdown(void) {
         if (c->mod13q) hipModuleUnload(c->mod13q);
         hp_destroy(c->pipe);
         for (int i = 0; i < WS_COUNT; ++i) if (c->ws[i]) hipFree(c->ws[i]);
+        for (int l = 0; l < Ctx::NLANE; ++l)
+            if (l != c->cur_lane)
+                for (int i = 0; i < WS_COUNT; ++i) if (i != WS_K1 && c->lanes[l].ws[i]) hipFree(c->lanes[l].ws[i]);
         if (c->async_status) hipFree(c->async_status);
         if (c->status_pin) hipHostFree(c->status_pin);
         for (auto& p : c->ring) { if (p.host) hipHostFree(p.host); if (p.ev) hipEventDestroy(p.ev); }
@@ -2628,6 +2674,19 @@ int ss_set_host_pipe(int threads, int64_t slot_bytes, int64_t chunk_bytes, int b
     return SS_OK;
 }
 
+int ss_workspace_lanes(int32_t* out, int32_t n) {
+    if (!out || n < 1) return fail(SS_EINVAL, "ss_workspace_lanes: out is NULL");
+    Ctx* c;
+    int rc = get_ctx(&c);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lock(c->mu);
+    int live = 0;
+    for (int i = 0; i < Ctx::NLANE; ++i) live += c->lanes[i].used ? 1 : 0;
+    const int32_t v[4] = {Ctx::NLANE, live, c->lane_switches, c->lane_evictions};
+    for (int i = 0; i < n && i < 4; ++i) out[i] = v[i];
+    return SS_OK;
+}
+
 int ss_host_path_stats(double* out, int32_t n) {
     if (!out || n < 1) return fail(SS_EINVAL, "ss_host_path_stats: out is NULL");
     Ctx* c;
@@ -2685,7 +2744,7 @@ int ss_async_status(int32_t* code, int64_t* where, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     // the status word is per device: the planner that may have latched it ran on the stream of the last render -- wait for THAT stream
     // first, or a poll through another stream could read the word before k_plan_explicit has run and miss the error
-    if (c->have_last && c->last_stream != stream) HIPCHK(hipStreamSynchronize(c->last_stream));
+    { const int rcl = sync_other_lanes(c, stream); if (rcl) return rcl; }
     int32_t h[4] = {0, 0, 0, 0};
     HIPCHK(hipMemcpyAsync(h, c->async_status, 16, hipMemcpyDeviceToHost, stream));
     HIPCHK(hipStreamSynchronize(stream));
@@ -2708,7 +2767,7 @@ int ss_plan_status_last(int32_t* out_of_range, int64_t* where, int32_t* too_irre
         return SS_OK;
     }
     hipStream_t stream = (hipStream_t)stream_;
-    if (c->have_last && c->last_stream != stream) HIPCHK(hipStreamSynchronize(c->last_stream));
+    { const int rcl = sync_other_lanes(c, stream); if (rcl) return rcl; }
     int32_t h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     HIPCHK(hipMemcpyAsync(h, c->async_status, 32, hipMemcpyDeviceToHost, stream));
     HIPCHK(hipStreamSynchronize(stream));

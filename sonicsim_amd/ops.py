@@ -91,6 +91,100 @@ def init(device: int = -1):
     _lib.check(_lib.load().ss_init(int(device)))
 
 
+# ---- independent renders on alternating streams (round 5) -----------------------------------------------------------------------------
+_active_streams = None
+
+
+class RenderStreams:
+    """Independent renders overlap each other's ends (SonicSet.py:77-94 issues five per sample, one after the other):
+
+        with ops.overlap_renders():                      # or RenderStreams(device, depth=2)
+            a = SonicSim_moving.interpolate_moving_audio(src1, irs1, pos1)     # ROCm tensors
+            b = SonicSim_moving.interpolate_moving_audio(src2, irs2, pos2)
+            c = SonicSim_moving.convolve_fixed_receiver(noise, ir_n)
+        # here the current stream has waited for all of them
+
+    A render is a spectra launch followed by ONE persistent launch whose workgroups leave one by one over its last ~20 us; on a single stream the
+    next render's spectra kernel starts only when the last of them has left.  Inside this context every device-tensor render entry point
+    (``convolve_moving_seg``, ``convolve_moving``, ``convolve_fixed`` and the drop-in functions on top of them) runs on the next of ``depth`` side
+    streams: the side stream first waits for everything the caller's stream has enqueued so far (inputs made inside the block are safe), the
+    caller's stream waits for the side streams when the block ends -- outputs must not be touched by other work before that.  The library keeps one
+    workspace lane per stream (``ss_workspace_lanes``), so nothing is shared between two renders in flight; outputs the CALLER supplies (``out=``)
+    must be distinct for renders that may overlap.  Same bits as the one-stream order.  ``next()`` gives the stream context explicitly, for callers
+    that put more than the render on it (bench.py: slot / render / submit of the scene gather)."""
+
+    def __init__(self, device=None, depth=2):
+        import torch
+        self.torch = torch
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self.depth = max(1, int(depth))
+        self.side = [torch.cuda.Stream(device=self.device) for _ in range(self.depth)]
+        self.ev = [torch.cuda.Event() for _ in range(4 * self.depth)]
+        self.i = 0
+        self.main = None
+        self.outs = []
+        self.busy = False
+        self._prev = None
+
+    def __enter__(self):
+        global _active_streams
+        self.main = self.torch.cuda.current_stream(self.device)
+        self._prev = _active_streams
+        _active_streams = self
+        self.outs = []
+        return self
+
+    def next(self):
+        """context manager: the torch current stream of this device is the next side stream, ordered behind everything the caller's stream holds now"""
+        s = self.side[self.i % self.depth]
+        ev = self.ev[self.i % len(self.ev)]
+        self.i += 1
+        ev.record(self.main)
+        s.wait_event(ev)
+        return self.torch.cuda.stream(s)
+
+    def join(self):
+        """the caller's stream waits for every render issued so far (called by __exit__)"""
+        for s in self.side:
+            self.main.wait_stream(s)
+        for y in self.outs:                      # tensors allocated under a side stream and used on the caller's from here on
+            y.record_stream(self.main)
+        self.outs = []
+
+    def __exit__(self, *exc):
+        global _active_streams
+        _active_streams = self._prev
+        self.join()
+        return False
+
+
+def overlap_renders(device=None, depth=2):
+    """``with ops.overlap_renders(): ...`` -- see RenderStreams"""
+    return RenderStreams(device, depth)
+
+
+def _overlappable(fn):
+    """render entry points: inside a RenderStreams block a call on device tensors runs on the next side stream"""
+    @functools.wraps(fn)
+    def wrap(*a, **k):
+        rs = _active_streams
+        if rs is None or rs.busy or not any(_is_dev(v) for v in a[:2]):
+            return fn(*a, **k)
+        t = next(v for v in a[:2] if _is_dev(v))
+        if t.device != rs.device or rs.torch.cuda.current_stream(rs.device) != rs.main:
+            return fn(*a, **k)                   # another device, or the caller already chose a stream itself (RenderStreams.next())
+        rs.busy = True
+        try:
+            with rs.next():
+                y = fn(*a, **k)
+        finally:
+            rs.busy = False
+        if _is_dev(y) and k.get("out") is None:
+            rs.outs.append(y)
+        return y
+    return wrap
+
+
 _PIN_POOL = {"free": {}, "bytes": 0, "cap": 256 << 20, "on": True}      # leased pinned output buffers (host-pointer renders)
 
 
@@ -206,6 +300,7 @@ def _out_ct(out, C, T, dev):
     return out
 
 
+@_overlappable
 @_restores_device
 def convolve_moving(x, rirs, idx, w, path=None, out=None, validate=True):
     """Row V (SonicSim_moving.py:63-96).  x (T,), rirs (P,C,L), idx (T,) int, w (T,) -> (C,T).
@@ -277,6 +372,13 @@ def set_task_queue(dynamic: bool):
     _lib.check(_lib.load().ss_set_task_queue(1 if dynamic else 0))
 
 
+def workspace_lanes():
+    """{lanes, in_use, switches, takeovers} of the current device's stream-private workspace lanes (a takeover = a stream synchronisation)"""
+    v = (ctypes.c_int32 * 4)()
+    _lib.check(_lib.load().ss_workspace_lanes(v, 4))
+    return {"lanes": v[0], "in_use": v[1], "switches": v[2], "takeovers": v[3]}
+
+
 def async_status(stream_of=None):
     """stream_of: a device tensor whose device's current stream is synchronised (default: the current device's current stream).
     (code, where) latched by renders issued with validate=False on the current device, then cleared: 0 = none,
@@ -302,6 +404,7 @@ def _check_moving_shapes(x, rirs, idx, w):
         raise ValueError("interp_index / interp_weight must have shape (audio_len,)")
 
 
+@_overlappable
 @_restores_device
 def convolve_moving_seg(x, rirs, seg_len, path=None, out=None, bank_peak=None, host_io=False):
     """Rows I+V fused (SonicSim_moving.py:42-45 + :63-96): seg_len (P-1,) host ints, sum == T.
@@ -418,6 +521,7 @@ def convolve_scene(xs, banks, segs, peaks=None, outs=None):
     return ys
 
 
+@_overlappable
 @_restores_device
 def convolve_fixed(x, h, path=None, out=None):
     """Row F (SonicSim_moving.py:47-61).  x (T,) or (1,T); h (C,L) -> (C,T)."""
