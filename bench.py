@@ -521,13 +521,15 @@ def run_cfg2(args, rank, local_rank, world, dev):
     bank, peak = ops.rir_bank_synth(sc.delay, sc.dgain, sc.L, sc.fs, sc.rt60, sc.bank_seed, device=dev, return_peak=True)   # K1 (row R)
     ops.divide_by_(bank, peak)                                                                        # row G, materialised
     x = torch.from_numpy(sc.x).to(dev)
-    scratch = [torch.empty((sc.C, sc.T), dtype=torch.float32, device=dev) for _ in range(2)]      # two renders may be in flight: one output each
-    # independent renders alternate over two streams (ops.RenderStreams: the library keeps a workspace lane per stream), so render i + 1's spectra
+    nstreams = max(1, min(3, int(os.environ.get("BENCH_STREAMS", "3"))))
+    scratch = [torch.empty((sc.C, sc.T), dtype=torch.float32, device=dev) for _ in range(nstreams)]      # renders in flight: one output each
+    # independent renders alternate over three streams (ops.RenderStreams: the library keeps a workspace lane per stream), so render i + 1's spectra
     # launch runs on the compute units render i's persistent launch frees one by one at its end; --serial / BENCH_SERIAL=1: one stream (the
     # profiler passes and the event windows, which time the render kernel ALONE, always run that way)
     import contextlib
     overlap = not (getattr(args, "serial", False) or os.environ.get("BENCH_SERIAL") == "1")
-    rstreams = ops.RenderStreams(dev, depth=2) if overlap else None
+    rstreams = ops.RenderStreams(dev, depth=nstreams) if overlap and nstreams > 1 else None
+    overlap = rstreams is not None
     if os.environ.get("BENCH_CALIB"):          # PMC passes (tools/profile.sh): streaming kernels of exactly known byte counts calibrate FETCH_SIZE / WRITE_SIZE
         calib = bank.clone()
         ops.peak_normalize_(calib)             # k_absmax reads 4PCL bytes; k_divide reads and writes 4PCL bytes
@@ -548,7 +550,7 @@ def run_cfg2(args, rank, local_rank, world, dev):
         with (rs if rs is not None else contextlib.nullcontext()):
             for i in range(k):
                 j = i // ge
-                out = scratch[i % 2]
+                out = scratch[i % nstreams]
                 with (rs.next() if rs is not None else contextlib.nullcontext()):      # slot / render / submit of step i on ITS stream
                     if sg is not None and i % ge == ge - 1 and j < ngath:
                         out = sg.slot(j)
@@ -715,9 +717,10 @@ def run_cfg2(args, rank, local_rank, world, dev):
         "value_cold": world * args.steps * audio_s / dt_cold,
         "ms_per_step_cold": dt_cold / args.steps * 1e3,
         "ms_per_step_latency": sorted(serial_windows)[len(serial_windows) // 2] if serial_windows else dt / args.steps * 1e3,
-        "streams": {"render_streams": 2 if overlap else 1,
-                    "how": ("independent renders alternate over two streams (ops.RenderStreams; one workspace lane per stream in the library): the next render's "
-                            "spectra launch fills the compute units the persistent launch frees at its end; ms_per_step_latency = the same K steps on ONE stream")
+        "streams": {"render_streams": nstreams if overlap else 1,
+                    "how": (f"independent renders alternate over {nstreams} streams (ops.RenderStreams; one workspace lane per stream in the library): the following "
+                            "renders' spectra launches fill the compute units a persistent launch frees at its end and the next persistent launch starts on them; "
+                            "ms_per_step_latency = the same K steps on ONE stream")
                            if overlap else "one stream (--serial)",
                     "ms_per_step_one_stream_windows": serial_windows, "workspace_lanes": ops.workspace_lanes()},
         "windows": {"count": nwin, "value_is": "median of the value windows (no HIP events inside them)",
@@ -735,7 +738,7 @@ def run_cfg2(args, rank, local_rank, world, dev):
         "config": {"workload": f"{args.config}: single moving source, {sc.C}-mic, {audio_s:.0f} s @ {sc.fs} Hz, "
                                f"{sc.P} trajectory points, {sc.L}-tap RIRs (T={sc.T})",
                    "T": sc.T, "P": sc.P, "C": sc.C, "L": sc.L, "fs": sc.fs,
-                   "entry_point": "ss_convolve_moving_seg_f32", "streams": 2 if overlap else 1, "parallelism": f"scene-sharded x{world}", "distributed": args.dist_info, "task_queue": "dynamic, one per XCD (the default; ss_set_task_queue)",
+                   "entry_point": "ss_convolve_moving_seg_f32", "streams": nstreams if overlap else 1, "parallelism": f"scene-sharded x{world}", "distributed": args.dist_info, "task_queue": "dynamic, one per XCD (the default; ss_set_task_queue)",
                    "gather": f"every {ge}th render of every rank to rank 0, overlapped with the next renders" if do_gather else False,
                    "value_is": f"sustained: the MEDIAN of {nwin} windows, each = W warm-up steps + exactly K timed steps between barrier + "
                                "synchronize, after an untimed pre-roll (all windows are listed under `windows`; the HIP events behind `roofline` "
@@ -957,6 +960,7 @@ def run_scenes(args, rank, local_rank, world, dev):
             ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
             np.random.seed(123 + rep)
             ev[0].record()
+            rend._ensure_set(sp_, 0)
             banks, peaks = rend._provide(sp_, 40_000 + rep, 0)
             ev[1].record()
             xs_ = [q[0] for q in sp_.speakers] + [q[0] for q in sp_.statics]

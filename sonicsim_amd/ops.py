@@ -93,12 +93,13 @@ def init(device: int = -1):
 
 # ---- independent renders on alternating streams (round 5) -----------------------------------------------------------------------------
 _active_streams = None
+_side_streams = {}
 
 
 class RenderStreams:
     """Independent renders overlap each other's ends (SonicSet.py:77-94 issues five per sample, one after the other):
 
-        with ops.overlap_renders():                      # or RenderStreams(device, depth=2)
+        with ops.overlap_renders():                      # or RenderStreams(device, depth=3)
             a = SonicSim_moving.interpolate_moving_audio(src1, irs1, pos1)     # ROCm tensors
             b = SonicSim_moving.interpolate_moving_audio(src2, irs2, pos2)
             c = SonicSim_moving.convolve_fixed_receiver(noise, ir_n)
@@ -110,15 +111,25 @@ class RenderStreams:
     streams: the side stream first waits for everything the caller's stream has enqueued so far (inputs made inside the block are safe), the
     caller's stream waits for the side streams when the block ends -- outputs must not be touched by other work before that.  The library keeps one
     workspace lane per stream (``ss_workspace_lanes``), so nothing is shared between two renders in flight; outputs the CALLER supplies (``out=``)
-    must be distinct for renders that may overlap.  Same bits as the one-stream order.  ``next()`` gives the stream context explicitly, for callers
+    must be distinct for renders that may overlap.  Same bits as the one-stream order.  depth: 3 (default) lets render i + 2's spectra launch run
+    under render i's tail, so that render i + 1's persistent launch finds its spectra ready and starts on the units render i frees -- measured at
+    config 2 (profiles/r05c): 0.1768 ms per render on one stream, 0.1709 with two, 0.1644 with three (the render kernel alone: 0.1622); the explicit
+    (idx, w) schedule planned on the device 0.2136 / 0.1896 / 0.1829.  ``next()`` gives the stream context explicitly, for callers
     that put more than the render on it (bench.py: slot / render / submit of the scene gather)."""
 
-    def __init__(self, device=None, depth=2):
+    def __init__(self, device=None, depth=3):
         import torch
+        if not 1 <= int(depth) <= 3:
+            raise ValueError("depth must be 1..3 (the library keeps four workspace lanes per device: the caller's stream + three)")
         self.torch = torch
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self.depth = max(1, int(depth))
-        self.side = [torch.cuda.Stream(device=self.device) for _ in range(self.depth)]
+        # the side streams of a device are created once and shared by every block: the library keeps ONE workspace lane per stream it has seen
+        # (four per device), so fresh streams per block would push live lanes out (each takeover is a stream synchronisation)
+        pool = _side_streams.setdefault((self.device.type, self.device.index), [])
+        while len(pool) < self.depth:
+            pool.append(torch.cuda.Stream(device=self.device))
+        self.side = pool[:self.depth]
         self.ev = [torch.cuda.Event() for _ in range(4 * self.depth)]
         self.i = 0
         self.main = None
@@ -158,7 +169,7 @@ class RenderStreams:
         return False
 
 
-def overlap_renders(device=None, depth=2):
+def overlap_renders(device=None, depth=3):
     """``with ops.overlap_renders(): ...`` -- see RenderStreams"""
     return RenderStreams(device, depth)
 
@@ -200,11 +211,32 @@ def set_pinned_outputs(on=True, cap_bytes=None):
 
 
 class _Lease:
-    __slots__ = ("ptr", "n", "__weakref__")
+    __slots__ = ("ptr", "cap", "__weakref__")
 
 
-def _lease_return(ptr, n):
-    _PIN_POOL["free"].setdefault(n, []).append(ptr)
+def _size_class(n):
+    """lease sizes are rounded up to 1/8-octave classes (<= 12.5 % slack): a dataset's varying lengths share a handful of buffers instead of
+    allocating one per distinct byte count (the exact-size free lists filled the cap with buffers no later request could use)"""
+    k = max(20, int(n - 1).bit_length() - 1)           # 2^k <= n - 1 < 2^(k + 1) for n > 2^20
+    step = 1 << (k - 3)
+    return -(-int(n) // step) * step
+
+
+def _lease_return(ptr, cap):
+    import time as _t
+    _PIN_POOL["free"].setdefault(cap, []).append((ptr, _t.monotonic()))
+
+
+def _pool_evict(need):
+    """free (ss_host_free) least-recently-returned idle buffers until `need` more bytes fit under the cap; False when they cannot"""
+    idle = sorted(((t, cap, ptr) for cap, lst in _PIN_POOL["free"].items() for (ptr, t) in lst))
+    for t, cap, ptr in idle:
+        if _PIN_POOL["bytes"] + need <= _PIN_POOL["cap"]:
+            break
+        _PIN_POOL["free"][cap].remove((ptr, t))
+        if _lib.load().ss_host_free(ctypes.c_void_p(ptr)) == 0:
+            _PIN_POOL["bytes"] -= cap
+    return _PIN_POOL["bytes"] + need <= _PIN_POOL["cap"]
 
 
 def _leased_pinned(shape):
@@ -212,20 +244,23 @@ def _leased_pinned(shape):
     n = int(np.prod(shape)) * 4
     if n < (1 << 20) or not _PIN_POOL["on"]:
         return None                      # small results: the staging copy is cheaper than the bookkeeping
-    free = _PIN_POOL["free"].get(n)
-    if free:
-        ptr = free.pop()
-    elif _PIN_POOL["bytes"] + n <= _PIN_POOL["cap"]:
+    cap = _size_class(n)
+    ptr = None
+    for c in sorted(k for k, lst in _PIN_POOL["free"].items() if lst and cap <= k <= cap + cap // 2):     # any idle buffer that is large enough
+        ptr, _ = _PIN_POOL["free"][c].pop()                                                                  # (and not wastefully larger)
+        cap = c
+        break
+    if ptr is None:
+        if _PIN_POOL["bytes"] + cap > _PIN_POOL["cap"] and not _pool_evict(cap):
+            return None                  # everything under the cap is on lease: a pageable array, as before
         p = ctypes.c_void_p()
-        if _lib.load().ss_host_alloc(ctypes.byref(p), n) != 0:
+        if _lib.load().ss_host_alloc(ctypes.byref(p), cap) != 0:
             return None
         ptr = p.value
-        _PIN_POOL["bytes"] += n
-    else:
-        return None
+        _PIN_POOL["bytes"] += cap
     lease = _Lease()
-    lease.ptr, lease.n = ptr, n
-    weakref.finalize(lease, _lease_return, ptr, n)
+    lease.ptr, lease.cap = ptr, cap
+    weakref.finalize(lease, _lease_return, ptr, cap)
     raw = (ctypes.c_char * n).from_address(ptr)
     raw._owner = lease                   # ndarray -> base (raw) -> lease: the buffer returns to the pool with the last view
     return np.frombuffer(raw, dtype=np.float32, count=n // 4).reshape(shape)

@@ -137,14 +137,24 @@ class SceneRenderer:
         self._set_free = [None, None]         # event after which set i may be overwritten (its render has finished)
 
     # ---- the provider (K1 x 5) of one scene into bank set `si`
-    def _provide(self, spec, seed, si):
+    def _ensure_set(self, spec, si):
+        """Bank set `si` with this scene's shapes.  ALWAYS called with the caller's stream current (never inside the side-stream context): the
+        caching allocator then owns the blocks on behalf of that stream, and the side stream's use is declared with record_stream.  A set is
+        replaced (other shapes) only after everything that may still read or write it has finished (the old tensors used to be dropped
+        while a render or the generator on the other stream could still be using them)."""
         import torch
         P = int(spec.speakers[0][1].shape[0])
-        if self._sets[si] is None or self._sets[si][0][0].shape != (P, spec.C, spec.L):
-            banks = [torch.empty((P, spec.C, spec.L), dtype=torch.float32, device=self.device) for _ in range(3)] + \
-                    [torch.empty((1, spec.C, spec.L), dtype=torch.float32, device=self.device) for _ in range(2)]
-            peaks = [torch.empty(1, dtype=torch.float32, device=self.device) for _ in range(3)]
-            self._sets[si] = (banks, peaks)
+        if self._sets[si] is not None and self._sets[si][0][0].shape == (P, spec.C, spec.L):
+            return
+        if self._sets[si] is not None:
+            torch.cuda.synchronize(self.device)      # rare (the scene shapes changed): nothing of the old set is in flight when it goes back to the allocator
+            self._set_free[si] = None
+        banks = [torch.empty((P, spec.C, spec.L), dtype=torch.float32, device=self.device) for _ in range(3)] + \
+                [torch.empty((1, spec.C, spec.L), dtype=torch.float32, device=self.device) for _ in range(2)]
+        peaks = [torch.empty(1, dtype=torch.float32, device=self.device) for _ in range(3)]
+        self._sets[si] = (banks, peaks)
+
+    def _provide(self, spec, seed, si):
         banks, peaks = self._sets[si]
         geoms = [(delay, dgain, rt60, (seed * 8 + k) & 0x7FFFFFFF) for k, (x, delay, dgain, seg, rt60) in enumerate(spec.speakers)] + \
                 [(delay, dgain, rt60, (seed * 8 + 4 + k) & 0x7FFFFFFF) for k, (x, delay, dgain, rt60) in enumerate(spec.statics)]
@@ -161,14 +171,17 @@ class SceneRenderer:
         si = self._set_next
         self._set_next ^= 1
         cur = torch.cuda.current_stream(self.device)
+        self._ensure_set(spec, si)                                 # (allocated under the caller's stream)
         self._k1_stream.wait_stream(cur)                           # behind the current scene's render launch
         if self._set_free[si] is not None:
             self._k1_stream.wait_event(self._set_free[si])
+        for t in self._sets[si][0] + self._sets[si][1]:
+            t.record_stream(self._k1_stream)                       # written by the side stream, read by the caller's
         with torch.cuda.stream(self._k1_stream):
             self._provide(spec, seed, si)
             ev = torch.cuda.Event()
             ev.record(self._k1_stream)
-        self._ready = ((id(spec), int(seed)), si, ev)
+        self._ready = ((spec, int(seed)), si, ev)                  # the spec OBJECT (kept alive), not its id(): an id can be reused after a collection
 
     def render(self, spec: SceneSpec, seed: int, sirs=(0.0,), snr=15.0, out=None, sync=True, next_scene=None):
         """K1 x 3 (bank + tracked peak) -> moving renders with the normalisation deferred; K1 x 2 -> static renders; loudness of
@@ -181,7 +194,7 @@ class SceneRenderer:
         if self.one_launch and spec.L > 4096:
             # the provider first (five K1 launches, or the prefetched set), then ALL five renders in one persistent launch (ss_convolve_scene_f32)
             cur = torch.cuda.current_stream(self.device)
-            if self._ready is not None and self._ready[0] == (id(spec), int(seed)):
+            if self._ready is not None and self._ready[0][0] is spec and self._ready[0][1] == int(seed):
                 _, si, ev = self._ready
                 self._ready = None
                 cur.wait_event(ev)
@@ -189,6 +202,7 @@ class SceneRenderer:
             else:
                 si = self._set_next
                 self._set_next ^= 1
+                self._ensure_set(spec, si)
                 if self._set_free[si] is not None:
                     cur.wait_event(self._set_free[si])
                 banks, peaks = self._provide(spec, seed, si)

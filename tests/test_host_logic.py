@@ -177,3 +177,53 @@ def test_loudness_oracle_mirrors_input_dtype():
     n64, _ = O.lufs_norm(a.astype(np.float64), 16000, -20)
     assert n32.dtype == np.float32 and n64.dtype == np.float64
     np.testing.assert_allclose(n32, n64, rtol=2e-7, atol=0)
+
+
+def test_pinned_output_pool_size_classes_and_eviction(monkeypatch):
+    """ADVICE r4 (ops._PIN_POOL): leases are rounded up to size classes, an idle buffer that is large enough is reused, and when the cap is
+    reached idle buffers are FREED (least recently returned first) instead of every later result silently falling back to pageable memory."""
+    import ctypes
+    import gc
+    from sonicsim_amd import _lib, ops
+
+    class FakeLib:
+        def __init__(self):
+            self.live = {}
+            self.allocs = self.frees = 0
+
+        def ss_host_alloc(self, pp, n):
+            buf = ctypes.create_string_buffer(int(n))
+            addr = ctypes.addressof(buf)
+            self.live[addr] = buf
+            ctypes.cast(pp, ctypes.POINTER(ctypes.c_void_p))[0] = addr
+            self.allocs += 1
+            return 0
+
+        def ss_host_free(self, p):
+            self.live.pop(p.value)
+            self.frees += 1
+            return 0
+    fake = FakeLib()
+    monkeypatch.setattr(_lib, "load", lambda: fake)
+    monkeypatch.setattr(ops, "_PIN_POOL", {"free": {}, "bytes": 0, "cap": 64 << 20, "on": True})
+    assert ops._leased_pinned((1, 1000)) is None                          # small results never lease
+    a = ops._leased_pinned((8, 960000))                                   # 30.72 MB -> a 31.46 MB class
+    assert a is not None and a.shape == (8, 960000) and fake.allocs == 1
+    a[:] = 1.0
+    del a
+    gc.collect()
+    b = ops._leased_pinned((8, 959000))                                   # a slightly different length reuses the same buffer
+    assert b is not None and fake.allocs == 1
+    c = ops._leased_pinned((8, 961000))                                   # b is on lease: a second buffer
+    assert c is not None and fake.allocs == 2 and ops._PIN_POOL["bytes"] <= 64 << 20
+    assert ops._leased_pinned((8, 960000)) is None                        # everything under the cap is on lease: pageable fallback, nothing freed
+    assert fake.frees == 0
+    del b, c
+    gc.collect()
+    d = ops._leased_pinned((4, 3_000_000))                                # 48 MB: does not fit beside the two idle 31 MB buffers -> they are evicted
+    assert d is not None and fake.frees >= 1 and ops._PIN_POOL["bytes"] <= 64 << 20
+    assert len(fake.live) == fake.allocs - fake.frees
+    lens = list(range(20 << 20, 40 << 20, 99_991))                        # a dataset's lengths: ~200 distinct byte counts between 20 and 40 MB
+    sizes = [ops._size_class(n) for n in lens]
+    assert all(s >= n and s <= n * 1.126 for s, n in zip(sizes, lens))
+    assert len(set(sizes)) <= 10                                          # ... fall into a handful of classes

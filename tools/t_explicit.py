@@ -22,7 +22,22 @@ def best(fn, k=50):
         for _ in range(k): fn()
         torch.cuda.synchronize(); ts.append((time.perf_counter() - t0) / k)
     return round(min(ts) * 1e3, 4)
+outs = [torch.empty_like(out) for _ in range(3)]
+def overlapped(fn, depth, k=60):
+    """the same calls as independent renders on `depth` alternating streams (ops.RenderStreams), one output per render in flight"""
+    def run(n):
+        with ops.RenderStreams(dev, depth=depth) as rs:
+            for i in range(n):
+                with rs.next():
+                    fn(outs[i % depth])
+    run(12); torch.cuda.synchronize(); ts = []
+    for _ in range(5):
+        t0 = time.perf_counter(); run(k); torch.cuda.synchronize(); ts.append((time.perf_counter() - t0) / k)
+    return round(min(ts) * 1e3, 4)
 r = {"implicit_seg_ms": best(lambda: ops.convolve_moving_seg(x, bank, seg, out=out)),
      "explicit_async_ms": best(lambda: ops.convolve_moving(x, bank, di, dw, out=out, validate=False)),
      "explicit_validating_ms": best(lambda: ops.convolve_moving(x, bank, di, dw, out=out))}
+for d in (2, 3):
+    r[f"implicit_seg_{d}_streams_ms"] = overlapped(lambda o: ops.convolve_moving_seg(x, bank, seg, out=o), d)
+    r[f"explicit_async_{d}_streams_ms"] = overlapped(lambda o: ops.convolve_moving(x, bank, di, dw, out=o, validate=False), d)
 print(json.dumps(r), flush=True)
