@@ -966,9 +966,9 @@ def run_scenes(args, rank, local_rank, world, dev):
             xs_ = [q[0] for q in sp_.speakers] + [q[0] for q in sp_.statics]
             ops.convolve_scene(xs_, banks, [q[3] for q in sp_.speakers] + [None, None], peaks=list(peaks) + [None, None], outs=[rend.stack[i] for i in range(5)])
             ev[2].record()
-            nstack, _res = A.get_lufs_norm_audio_batch(rend.stack, sp_.fs, pipeline.LUFS_TARGETS, allow_many_channels=True, sync=False)
+            nstack, _res, sq_ = A.get_lufs_norm_audio_batch(rend.stack, sp_.fs, pipeline.LUFS_TARGETS, allow_many_channels=True, sync=False, want_sumsq=True)
             ev[3].record()
-            mixing.mix_sources(nstack[:2], nstack[3][None], np.asarray([1.5], np.float32), 15.0, keep_speakers=True)
+            mixing.mix_sources(nstack[:2], nstack[3][None], np.asarray([1.5], np.float32), 15.0, keep_speakers=True, presums=(sq_[:2], sq_[3:4]))
             ev[4].record()
             torch.cuda.synchronize()
             if rep >= 2:
@@ -979,7 +979,7 @@ def run_scenes(args, rank, local_rank, world, dev):
                   for k_, v_ in acc.items()}
         stages["note"] = ("stages launched one after the other on one stream with torch events between them (no provider prefetch), mean of 8 scenes; bytes: K1 = the "
                           "banks it writes, render = SURVEY 8d's render bytes + the zero fill of the five stems, loudness = read + write of five stems, mix = read 3 + "
-                          "write 1; the sum exceeds ms_per_step because the timed region overlaps the next scene's K1 with loudness / mix")
+                          "write 1 (round 5: the stems' energies ride on the loudness scale pass, ss_mix_presum_f32); the sum exceeds ms_per_step because the timed region overlaps the next scene's K1 with loudness / mix")
     except Exception as e:                                   # noqa: BLE001 -- informational
         stages = {"error": repr(e)}
     roof["scene"]["stages"] = stages

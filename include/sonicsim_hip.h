@@ -321,6 +321,22 @@ int ss_lufs_norm_batch_f32(const float* audio, float* out, int64_t T, int32_t C,
                            double block_norm, const double* weights, const double* targets,
                            double* result, uint32_t flags, void* stream);
 
+/* ---- rows U + M back to back (SonicSet.py:97-101 normalises the stems, movingdatamodule.py:105-124 mixes them): the energy the mix needs of
+ * every stem rides on the pass that writes the normalised stem.
+ * ss_lufs_norm_batch_sq_f32 = ss_lufs_norm_batch_f32 with SS_FLAG_DEVICE_PTR | SS_FLAG_RESULT_DEVICE (no synchronisation) that also leaves
+ * sum(out[s]^2) (float64, every element of stem s) in the DEVICE array sumsq[S].
+ * ss_mix_presum_f32 = ss_mix_f32 for ONE noise stem whose speaker / noise energies are already known (device doubles sumsq_speakers[S],
+ * sumsq_noise[1], e.g. entries of the array above): two launches instead of five, 184 MB instead of 276 MB of traffic for a 2-speaker
+ * 8 x 960 000 mix.  The same arithmetic per sample as ss_mix_f32; the energies are float64 sums in another association, so a gain may differ
+ * from ss_mix_f32's in its last bit (the north-star gate is 1e-4).  Device pointers, 16-byte aligned stems, n % 4 == 0; gains_dev (optional,
+ * device, S + 1 floats) receives {1, interferer gains..., noise gain}.  SS_FLAG_KEEP_SPEAKERS as in ss_mix_f32. */
+int ss_lufs_norm_batch_sq_f32(const float* audio, float* out, int64_t T, int32_t C, int32_t S,
+                              const double* coef, const int64_t* lo, const int64_t* hi, int32_t nblocks,
+                              double block_norm, const double* weights, const double* targets,
+                              double* result, double* sumsq, uint32_t flags, void* stream);
+int ss_mix_presum_f32(float* speakers, int32_t S, const float* noise, int64_t n, const float* sirs, float snr, float* mix,
+                      const double* sumsq_speakers, const double* sumsq_noise, float* gains_dev, uint32_t flags, void* stream);
+
 /* ---- measurement hooks (bench.py): HIP-event timing of the dominant kernels on their own stream.
  * kind 0 = overlap-save render kernel (one parity pass = one launch), 1 = input-spectra kernel,
  * 2 = direct-form kernel.  ss_prof_enable(0) = off, 1 = every launch, N > 1 = every N-th launch of each

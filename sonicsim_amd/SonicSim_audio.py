@@ -182,7 +182,7 @@ def lufs_norm(data, sr, norm=-6, allow_many_channels: bool = False, channel_firs
     return norm_data, gain
 
 
-def get_lufs_norm_audio_batch(stems, sr=16000, lufs=(-6,), allow_many_channels: bool = False, sync: bool = True):
+def get_lufs_norm_audio_batch(stems, sr=16000, lufs=(-6,), allow_many_channels: bool = False, sync: bool = True, want_sumsq: bool = False):
     """Extension: ``get_lufs_norm_audio`` for a stack of stems (S, C, T) in ONE device call.  The class loudness of stem i
     is drawn from the global NumPy RNG in stem order, exactly as S successive reference calls (:83-86) would draw them.
     Returns (normalised stack (S, C, T), [gain_0, ...]).  sync=False (device stacks): the call only enqueues work and returns the raw
@@ -195,6 +195,8 @@ def get_lufs_norm_audio_batch(stems, sr=16000, lufs=(-6,), allow_many_channels: 
     targets = [np.random.uniform(l - 2, l + 2) for l in lufs]
     block_size = 0.4 if T / sr >= 0.4 else T / sr
     _, lo, hi, weights, _ = _meter_args(stems[0], sr, block_size, allow_many_channels, True)
+    if not sync and want_sumsq:          # (out, records, sum(out[s] ** 2) per stem on the device: what the mix of these stems needs, ops.mix(presums=))
+        return ops.lufs_norm(stems, _kw_coef(float(sr)), lo, hi, block_size * sr, weights, targets, layout_tc=False, result_device=True, want_sumsq=True)
     if not sync:
         out, res = ops.lufs_norm(stems, _kw_coef(float(sr)), lo, hi, block_size * sr, weights, targets, layout_tc=False, result_device=True)
         return out, res                 # (S, 4) float64 on the device: {loudness, linear gain, sum(out), sum(in)}; see lufs_gains_from_result

@@ -107,6 +107,11 @@ _SIGS = {
     "ss_lufs_norm_batch_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, c_f64p,
                                               c_i64p, c_i64p, ctypes.c_int32, ctypes.c_double, c_f64p, c_f64p, ctypes.c_void_p, ctypes.c_uint32,
                                               ctypes.c_void_p]),
+    "ss_lufs_norm_batch_sq_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, c_f64p,
+                                                 c_i64p, c_i64p, ctypes.c_int32, ctypes.c_double, c_f64p, c_f64p, ctypes.c_void_p, ctypes.c_void_p,
+                                                 ctypes.c_uint32, ctypes.c_void_p]),
+    "ss_mix_presum_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int64, c_f32p, ctypes.c_float, ctypes.c_void_p,
+                                         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p]),
     "ss_prof_enable": (ctypes.c_int, [ctypes.c_int]),
     "ss_prof_read": (ctypes.c_int, [ctypes.c_int, c_i64p, c_f64p]),
     "ss_prof_seen": (ctypes.c_int, [ctypes.c_int, c_i64p]),

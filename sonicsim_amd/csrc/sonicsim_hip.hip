@@ -733,9 +733,20 @@ __device__ unsigned long long g_dbg_clk[8][2][256];
 #endif
 // SS_FLAG_RESULT_DEVICE: {loudness, gain, sum(out), sum(in)} of stem g straight into a caller's device array -- the final additions in
 // k_final_sum's association (64 strided lanes, then a butterfly), so host-finished and device-finished sums are the same bits
-__global__ __launch_bounds__(64) void k_lufs_result(const double* __restrict__ res, const double* __restrict__ part, int nb, double* __restrict__ out) {
+__device__ __forceinline__ double wave_final_sum(const double* __restrict__ partial, int nb, int lane) {
+    double s = 0.0;
+    for (int i = lane; i < nb; i += 64) s += partial[i];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    return s;
+}
+__global__ __launch_bounds__(64) void k_lufs_result(const double* __restrict__ res, const double* __restrict__ part, int nb, double* __restrict__ out,
+                                                    const double* __restrict__ part_sq = nullptr, double* __restrict__ sumsq = nullptr) {
     const int g = blockIdx.x;
     double s0 = 0.0, s1 = 0.0;
+    if (part_sq) {                   // sum(out^2) of stem g for the mix that follows (ss_mix_presum_f32)
+        const double v = wave_final_sum(part_sq + (int64_t)g * nb, nb, (int)threadIdx.x);
+        if (threadIdx.x == 0) sumsq[g] = v;
+    }
     for (int i = threadIdx.x; i < nb; i += 64) {
         s0 += part[((int64_t)2 * g + 0) * nb + i];
         s1 += part[((int64_t)2 * g + 1) * nb + i];
@@ -762,8 +773,10 @@ __global__ __launch_bounds__(64) void k_final_sum(const double* __restrict__ par
 // blockIdx.y = group (stem): its n elements start at group * n, its gain is gain_dev[4 * group], its partial sums go to
 // partial[(2 * group + {0,1}) * gridDim.x + blockIdx.x].
 __global__ __launch_bounds__(256) void k_scale_sums(const float* __restrict__ in, float* __restrict__ out, int64_t n, float gain,
-                                                    const double* __restrict__ gain_dev, double* __restrict__ partial /*[groups][2][grid]*/) {
-    __shared__ double sw[2][4];
+                                                    const double* __restrict__ gain_dev, double* __restrict__ partial /*[groups][2][grid]*/,
+                                                    double* __restrict__ partial_sq = nullptr /*[groups][grid]: sum(out^2), or null*/) {
+    __shared__ double sw[3][4];
+    double sq = 0.0;                 // round 5: the energy the mix needs of every normalised stem rides on the pass that writes it (ss_mix_presum_f32)
     if (gain_dev) gain = (float)gain_dev[4 * blockIdx.y];
     in += (int64_t)blockIdx.y * n;
     out += (int64_t)blockIdx.y * n;
@@ -781,12 +794,14 @@ __global__ __launch_bounds__(256) void k_scale_sums(const float* __restrict__ in
             out4[i] = o;
             so += ((double)o.x + (double)o.y) + ((double)o.z + (double)o.w);
             si += ((double)v.x + (double)v.y) + ((double)v.z + (double)v.w);
+            sq += ((double)o.x * (double)o.x + (double)o.y * (double)o.y) + ((double)o.z * (double)o.z + (double)o.w * (double)o.w);
         }
         for (int64_t i = (n4 << 2) + tid; i < n; i += stride) {
             const float v = in[i], o = gain * v;
             out[i] = o;
             so += (double)o;
             si += (double)v;
+            sq += (double)o * (double)o;
         }
     } else {
         for (int64_t i = tid; i < n; i += stride) {
@@ -795,14 +810,16 @@ __global__ __launch_bounds__(256) void k_scale_sums(const float* __restrict__ in
             out[i] = o;
             so += (double)o;
             si += (double)v;
+            sq += (double)o * (double)o;
         }
     }
-    for (int o = 32; o > 0; o >>= 1) { so += __shfl_xor(so, o); si += __shfl_xor(si, o); }
-    if ((threadIdx.x & 63) == 0) { sw[0][threadIdx.x >> 6] = so; sw[1][threadIdx.x >> 6] = si; }
+    for (int o = 32; o > 0; o >>= 1) { so += __shfl_xor(so, o); si += __shfl_xor(si, o); sq += __shfl_xor(sq, o); }
+    if ((threadIdx.x & 63) == 0) { sw[0][threadIdx.x >> 6] = so; sw[1][threadIdx.x >> 6] = si; sw[2][threadIdx.x >> 6] = sq; }
     __syncthreads();
     if (threadIdx.x == 0) {
         partial[blockIdx.x] = (sw[0][0] + sw[0][1]) + (sw[0][2] + sw[0][3]);
         partial[gridDim.x + blockIdx.x] = (sw[1][0] + sw[1][1]) + (sw[1][2] + sw[1][3]);
+        if (partial_sq) partial_sq[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = (sw[2][0] + sw[2][1]) + (sw[2][2] + sw[2][3]);
     }
 }
 
@@ -812,12 +829,6 @@ __device__ __forceinline__ double rms_db_from_sumsq(double ss_, double n) {
 }
 
 // one wave adds nb partial sums in k_final_sum's association (64 strided lanes, then a butterfly); every lane gets the sum
-__device__ __forceinline__ double wave_final_sum(const double* __restrict__ partial, int nb, int lane) {
-    double s = 0.0;
-    for (int i = lane; i < nb; i += 64) s += partial[i];
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-    return s;
-}
 // mix step 2: interferer gains from speaker energies (movingdatamodule.py:106-113); finishes the energy sums itself
 // (partial[S][nb], wave per speaker) instead of a separate final-sum launch
 struct SirTab { float v[64]; };        // the S - 1 drawn SIRs travel in the kernel arguments (an upload costs a 4 us copy + a 6 us boundary)
@@ -918,6 +929,74 @@ __global__ __launch_bounds__(128) void k_mix_gains2(const double* __restrict__ p
         g[S] = (float)pow(10.0, gain / 20.0);
     }
 }
+// ---- round 5: the mix of a scene whose stems come straight out of the loudness pass (ss_mix_presum_f32).  sum(x^2) of every stem was
+// accumulated by the pass that wrote it (k_scale_sums), so the energy pass over the speakers and both one-workgroup gain kernels disappear:
+// every workgroup derives the interferer gains from the S sums itself, and the second pass reduces the first one's partial sums itself.
+// Same arithmetic per sample as k_mix_scale_sum4 / k_mix_final (movingdatamodule.py:105-124); two launches instead of five.
+__global__ __launch_bounds__(256) void k_mix_pre_scale_sum4(float* __restrict__ spk, int S, int64_t n4, const double* __restrict__ sumsq,
+                                                            double n_elems, const SirTab sir_tab, float* __restrict__ mix,
+                                                            double* __restrict__ partial /*[grid]*/, float* __restrict__ g_out, int write_back) {
+    __shared__ double sw[4];
+    __shared__ float gs_[64];
+    if ((int)threadIdx.x < S) {
+        float g = 1.0f;
+        if (threadIdx.x >= 1) {
+            const double e0 = rms_db_from_sumsq(sumsq[0], n_elems), ei = rms_db_from_sumsq(sumsq[threadIdx.x], n_elems);
+            double gain = e0 - ei - (double)sir_tab.v[threadIdx.x - 1];
+            gain = gain < 40.0 ? gain : 40.0;
+            g = (float)pow(10.0, gain / 20.0);
+        }
+        gs_[threadIdx.x] = g;
+        if (blockIdx.x == 0) g_out[threadIdx.x] = g;
+    }
+    __syncthreads();
+    double e_s = 0.0;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    float4* spk4 = reinterpret_cast<float4*>(spk);
+    float4* mix4 = reinterpret_cast<float4*>(mix);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+        float4 sp = spk4[i];
+        for (int s = 1; s < S; ++s) {
+            const float gs = gs_[s];
+            float4 v = spk4[(int64_t)s * n4 + i];
+            v.x *= gs; v.y *= gs; v.z *= gs; v.w *= gs;
+            if (write_back) spk4[(int64_t)s * n4 + i] = v;
+            sp.x += v.x; sp.y += v.y; sp.z += v.z; sp.w += v.w;
+        }
+        mix4[i] = sp;
+        e_s += ((double)sp.x * (double)sp.x + (double)sp.y * (double)sp.y) + ((double)sp.z * (double)sp.z + (double)sp.w * (double)sp.w);
+    }
+    for (int o = 32; o > 0; o >>= 1) e_s += __shfl_xor(e_s, o);
+    if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = e_s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (sw[0] + sw[1]) + (sw[2] + sw[3]);
+}
+__global__ __launch_bounds__(256) void k_mix_pre_final4(const float* __restrict__ noise, int64_t n4, const double* __restrict__ partial, int nb,
+                                                        double n_elems, const double* __restrict__ sumsq_noise, float snr,
+                                                        float* __restrict__ mix, float* __restrict__ g_out /*[S + 1]*/, int S) {
+    __shared__ float gn_;
+    if (threadIdx.x < 64) {
+        const double es = wave_final_sum(partial, nb, (int)threadIdx.x);
+        if (threadIdx.x == 0) {
+            double gain = rms_db_from_sumsq(es, n_elems) - rms_db_from_sumsq(sumsq_noise[0], n_elems) - (double)snr;
+            gain = gain < 40.0 ? gain : 40.0;
+            gn_ = (float)pow(10.0, gain / 20.0);
+            if (blockIdx.x == 0) g_out[S] = gn_;
+        }
+    }
+    __syncthreads();
+    const float gn = gn_;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    const float4* noi4 = reinterpret_cast<const float4*>(noise);
+    float4* mix4 = reinterpret_cast<float4*>(mix);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+        const float4 nz = noi4[i];
+        float4 m = mix4[i];
+        m.x = m.x + (0.0f + nz.x) * gn; m.y = m.y + (0.0f + nz.y) * gn; m.z = m.z + (0.0f + nz.z) * gn; m.w = m.w + (0.0f + nz.w) * gn;
+        mix4[i] = m;
+    }
+}
+
 __global__ __launch_bounds__(256) void k_mix_final(const float* __restrict__ noises, int N, int64_t n, const float* __restrict__ g,
                                                    int S, float* __restrict__ mix) {
     const float gn = g[S];
@@ -1558,7 +1637,7 @@ int fail(int code, const char* fmt, ...) {
 
 #include "hostpipe.h"
 
-enum WsSlot { WS_XS, WS_PLAN, WS_BMIN, WS_BMAX, WS_X, WS_BANK, WS_IDX, WS_W, WS_Y, WS_SCR, WS_SCR2, WS_FILT, WS_META, WS_CNT, WS_LUFS, WS_RES, WS_KWP, WS_KWT, WS_GW, WS_DPLAN, WS_DTASKS, WS_K1, WS_COUNT };
+enum WsSlot { WS_XS, WS_PLAN, WS_BMIN, WS_BMAX, WS_X, WS_BANK, WS_IDX, WS_W, WS_Y, WS_SCR, WS_SCR2, WS_FILT, WS_META, WS_CNT, WS_LUFS, WS_RES, WS_KWP, WS_KWT, WS_GW, WS_DPLAN, WS_DTASKS, WS_K1, WS_SQ, WS_COUNT };
 
 struct Pinned {
     void* host = nullptr;
@@ -3130,6 +3209,34 @@ int ss_mix_f32(float* speakers, int32_t S, const float* noises, int32_t N, int64
     return SS_OK;
 }
 
+int ss_mix_presum_f32(float* speakers, int32_t S, const float* noise, int64_t n, const float* sirs, float snr, float* mix,
+                      const double* sumsq_speakers, const double* sumsq_noise, float* gains_dev, uint32_t flags, void* stream_) {
+    if (S < 1 || S > 64 || n <= 0 || !speakers || !noise || !mix || !sumsq_speakers || !sumsq_noise || (S > 1 && !sirs)) return fail(SS_EINVAL, "bad argument");
+    if (!(flags & SS_FLAG_DEVICE_PTR)) return fail(SS_EINVAL, "device pointers only (SS_FLAG_DEVICE_PTR): the stem energies are device-side by-products");
+    if (n % 4 != 0 || (((uintptr_t)speakers | (uintptr_t)noise | (uintptr_t)mix) & 15) != 0)
+        return fail(SS_EINVAL, "ss_mix_presum_f32 needs 16-byte aligned stems of a multiple of four samples (use ss_mix_f32)");
+    Ctx* c;
+    int rc = get_ctx(&c);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(c->mu);
+    hipStream_t stream = (hipStream_t)stream_;
+    if ((rc = stream_enter(c, stream))) return rc;
+    const int write_back = (flags & SS_FLAG_KEEP_SPEAKERS) ? 0 : 1;
+    const int nb = grid_for(n, 512);                      // (the grid of ss_mix_f32's pass: the same partial sums of the speech energy)
+    if ((rc = ws_ensure(c, WS_SCR, sizeof(double) * (size_t)nb))) return rc;
+    if ((rc = ws_ensure(c, WS_SCR2, sizeof(float) * ((size_t)S + 1) + 16))) return rc;
+    float* d_g = gains_dev ? gains_dev : (float*)c->ws[WS_SCR2];
+    SirTab sir_tab;
+    memset(&sir_tab, 0, sizeof(sir_tab));
+    for (int i = 0; i + 1 < S; ++i) sir_tab.v[i] = sirs[i];
+    hipLaunchKernelGGL(k_mix_pre_scale_sum4, dim3(nb), dim3(256), 0, stream, speakers, S, n / 4, sumsq_speakers, (double)n, sir_tab, mix,
+                       (double*)c->ws[WS_SCR], d_g, write_back);
+    hipLaunchKernelGGL(k_mix_pre_final4, dim3(grid_for(n / 4)), dim3(256), 0, stream, noise, n / 4, (const double*)c->ws[WS_SCR], nb, (double)n,
+                       sumsq_noise, snr, mix, d_g, S);
+    HIPCHK(hipGetLastError());
+    return SS_OK;
+}
+
 // K-weighting coefficients -> KwCoef (normalised biquads + the powers of the chunk transition matrix the scan needs)
 static int kw_setup(const double* coef, KwCoef& k) {
     // the tables depend on the 12 coefficients only (one set per sample rate): reuse the last set's tables
@@ -3316,9 +3423,11 @@ int ss_kweighted_block_power_f32(const float* audio, int64_t T, int32_t C, const
     return SS_OK;
 }
 
-int ss_lufs_norm_batch_f32(const float* audio, float* out, int64_t T, int32_t C, int32_t S, const double* coef, const int64_t* lo,
+static int lufs_norm_batch(const float* audio, float* out, int64_t T, int32_t C, int32_t S, const double* coef, const int64_t* lo,
                            const int64_t* hi, int32_t nblocks, double block_norm, const double* weights, const double* targets,
-                           double* result, uint32_t flags, void* stream_) {
+                           double* result, uint32_t flags, void* stream_, double* sumsq_dev /* device [S]: sum(out^2) per stem, or null */) {
+    if (sumsq_dev && (flags & (SS_FLAG_DEVICE_PTR | SS_FLAG_RESULT_DEVICE)) != (SS_FLAG_DEVICE_PTR | SS_FLAG_RESULT_DEVICE))
+        return fail(SS_EINVAL, "the stem energies are a device-side by-product: SS_FLAG_DEVICE_PTR | SS_FLAG_RESULT_DEVICE");
     if (!audio || !out || T <= 0 || C < 1 || S < 1 || S > 16 || (int64_t)C * S > 64 || !coef || nblocks < 0 || (nblocks && (!lo || !hi)) ||
         !weights || !targets || !result || !(block_norm > 0))
         return fail(SS_EINVAL, "bad argument");
@@ -3372,11 +3481,16 @@ int ss_lufs_norm_batch_f32(const float* audio, float* out, int64_t T, int32_t C,
     hipLaunchKernelGGL(k_gate, dim3(S), dim3(1024), use_lds ? gate_lds : 0, stream, (const double*)zdev, (int)C, (int)nblocks,
                        (const double*)c->ws[WS_GW], gt, zdev + (size_t)CC * nblocks, use_lds, res);
     double* part = res + 4 * (size_t)S;
-    hipLaunchKernelGGL(k_scale_sums, dim3(nb, S), dim3(256), 0, stream, (const float*)da, dout, ng, 0.f, (const double*)(res + 1), part);
+    double* part_sq = nullptr;
+    if (sumsq_dev) {
+        if ((rc = ws_ensure(c, WS_SQ, sizeof(double) * (size_t)S * nb))) return rc;
+        part_sq = (double*)c->ws[WS_SQ];
+    }
+    hipLaunchKernelGGL(k_scale_sums, dim3(nb, S), dim3(256), 0, stream, (const float*)da, dout, ng, 0.f, (const double*)(res + 1), part, part_sq);
     HIPCHK(hipGetLastError());
     if (flags & SS_FLAG_RESULT_DEVICE) {      // no host synchronisation: the four numbers per stem land in the caller's device array
         if (!dev) return fail(SS_EINVAL, "SS_FLAG_RESULT_DEVICE needs SS_FLAG_DEVICE_PTR");
-        hipLaunchKernelGGL(k_lufs_result, dim3(S), dim3(64), 0, stream, (const double*)res, (const double*)part, nb, result);
+        hipLaunchKernelGGL(k_lufs_result, dim3(S), dim3(64), 0, stream, (const double*)res, (const double*)part, nb, result, (const double*)part_sq, sumsq_dev);
         HIPCHK(hipGetLastError());
         return SS_OK;
     }
@@ -3400,6 +3514,19 @@ int ss_lufs_norm_batch_f32(const float* audio, float* out, int64_t T, int32_t C,
         }
     }
     return SS_OK;
+}
+
+int ss_lufs_norm_batch_f32(const float* audio, float* out, int64_t T, int32_t C, int32_t S, const double* coef, const int64_t* lo,
+                           const int64_t* hi, int32_t nblocks, double block_norm, const double* weights, const double* targets,
+                           double* result, uint32_t flags, void* stream_) {
+    return lufs_norm_batch(audio, out, T, C, S, coef, lo, hi, nblocks, block_norm, weights, targets, result, flags, stream_, nullptr);
+}
+
+int ss_lufs_norm_batch_sq_f32(const float* audio, float* out, int64_t T, int32_t C, int32_t S, const double* coef, const int64_t* lo,
+                              const int64_t* hi, int32_t nblocks, double block_norm, const double* weights, const double* targets,
+                              double* result, double* sumsq, uint32_t flags, void* stream_) {
+    if (!sumsq) return fail(SS_EINVAL, "sumsq is NULL");
+    return lufs_norm_batch(audio, out, T, C, S, coef, lo, hi, nblocks, block_norm, weights, targets, result, flags, stream_, sumsq);
 }
 
 int ss_lufs_norm_f32(const float* audio, float* out, int64_t T, int32_t C, const double* coef, const int64_t* lo, const int64_t* hi,

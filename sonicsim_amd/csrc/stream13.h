@@ -10,7 +10,7 @@
 // workgroup forms the current block's spectrum X_j from xh + the new samples (future samples = 0: outputs up to the newest sample do
 // not depend on them), accumulates  A_e = sum_p X_{j-p} . H_{row k+e, p}  for the segment's two rows e = 0, 1 (X loaded once for both),
 // runs the two inverse transforms and stores  y[t] = (1 - w[t]) a_0[t] + w[t] a_1[t]  for the piece's samples -- the reference's
-// gather + lerp (SonicSim_moving.py:89-94) with its bit-exact ramp w = float(double(t - s_k) / double(n_k)) (:43).  No atomics, no
+// gather + lerp (SonicSim_moving.py:89-94) with its bit-exact ramp w = float(double(t - s_k) * (1.0 / double(n_k))) (:43: np.linspace multiplies by the step, it does not divide).  No atomics, no
 // zero fill, deterministic.  Same transforms, slot order and tables as geometry 13 (tvfir13.h), so the bodies below also run on the
 // CPU workgroup emulator (tests/emul).
 #pragma once

@@ -18,7 +18,8 @@ def compute_mch_rms_dB(mch_wav, fs=16000, energy_thresh=-50):
     return ops.rms_db(mch_wav)
 
 
-def mix_sources(speaker_wav, noise_wav, sirs=None, snr=None, sir_range=(-6.0, 6.0), snr_range=(10.0, 20.0), out=None, keep_speakers=False):
+def mix_sources(speaker_wav, noise_wav, sirs=None, snr=None, sir_range=(-6.0, 6.0), snr_range=(10.0, 20.0), out=None, keep_speakers=False,
+                presums=None):
     """movingdatamodule.py:105-124.
     speaker_wav (S, [C,] T), noise_wav (N, [C,] T) float32 (torch or NumPy).  When ``sirs`` / ``snr`` are None
     they are drawn from the torch RNG exactly like the reference (``torch.Tensor(n).uniform_(a, b)``, :106/:119).
@@ -31,5 +32,5 @@ def mix_sources(speaker_wav, noise_wav, sirs=None, snr=None, sir_range=(-6.0, 6.
     if snr is None:
         snr = float(torch.Tensor(1).uniform_(*snr_range).numpy()[0])
     mix, spk, _ = ops.mix(speaker_wav, noise_wav, np.asarray(sirs, dtype=np.float32), float(snr), want_gains=False, out=out,
-                          keep_speakers=keep_speakers)                                                             # no host synchronisation
+                          keep_speakers=keep_speakers, presums=presums)                                                             # no host synchronisation
     return mix, spk

@@ -766,14 +766,17 @@ def rms_db(x):
 
 
 @_restores_device
-def mix(speaker_wav, noise_wav, sirs, snr, want_gains=True, out=None, keep_speakers=False):
+def mix(speaker_wav, noise_wav, sirs, snr, want_gains=True, out=None, keep_speakers=False, presums=None):
     """Row M (movingdatamodule.py:105-124).  speaker_wav (S,...), noise_wav (N,...) same trailing shape.
     Returns (mix, speaker_wav_scaled, gains).  A contiguous float32 device ``speaker_wav`` is scaled IN PLACE like the reference
     (:113); any other device input is first copied to that form (the returned tensor is then the scaled copy).
     want_gains=False skips the D2H copy of the gains and with it the only host synchronisation (gains is None).
     out (device form): a contiguous float32 tensor shaped like one stem to receive the mix (e.g. a gather slot).
     keep_speakers=True (device form): ``speaker_wav`` is read only -- the interferers are scaled on the fly for the mix and not written
-    back (a scene generator keeps its normalised stems without cloning them first); the returned speaker tensor is then the input."""
+    back (a scene generator keeps its normalised stems without cloning them first); the returned speaker tensor is then the input.
+    presums=(speaker_sumsq (S,), noise_sumsq (1,)) (device form, one noise stem, want_gains=False): float64 device tensors with sum(x ** 2) of the
+    stems -- by-products of ``lufs_norm(..., want_sumsq=True)`` -- so the mix does not measure them again (``ss_mix_presum_f32``: two launches
+    instead of five); stems that are not 16-byte aligned / a multiple of four samples take the ordinary path."""
     lib = _lib.load()
     sirs = np.ascontiguousarray(np.asarray(sirs, dtype=np.float32).reshape(-1))
     if _is_dev(speaker_wav):
@@ -790,6 +793,15 @@ def mix(speaker_wav, noise_wav, sirs, snr, want_gains=True, out=None, keep_speak
             raise ValueError("out must be a contiguous float32 device tensor shaped like one stem")
         gains = np.zeros(S, dtype=np.float32) if want_gains else None
         _set_device(spk)
+        if (presums is not None and not want_gains and N == 1 and n % 4 == 0 and spk.data_ptr() % 16 == 0 and noi.data_ptr() % 16 == 0
+                and out.data_ptr() % 16 == 0):
+            ps, pn = presums
+            if not (_is_dev(ps) and _is_dev(pn) and ps.dtype == torch.float64 and pn.dtype == torch.float64 and ps.numel() == S and pn.numel() == 1
+                    and ps.is_contiguous()):
+                raise ValueError("presums = (float64 device tensor (S,), float64 device tensor (1,))")
+            _lib.check(lib.ss_mix_presum_f32(_ptr(spk), S, _ptr(noi), n, sirs.ctypes.data_as(_lib.c_f32p), float(snr), _ptr(out), _ptr(ps), _ptr(pn), None,
+                                             _lib.FLAG_DEVICE_PTR | (_lib.FLAG_KEEP_SPEAKERS if keep_speakers else 0), _stream_ptr(spk)))
+            return out, spk, None
         _lib.check(lib.ss_mix_f32(_ptr(spk), S, _ptr(noi), N, n, sirs.ctypes.data_as(_lib.c_f32p), float(snr), _ptr(out),
                                   gains.ctypes.data_as(_lib.c_f32p) if want_gains else None,
                                   _lib.FLAG_DEVICE_PTR | (_lib.FLAG_KEEP_SPEAKERS if keep_speakers else 0), _stream_ptr(spk)))
@@ -839,12 +851,14 @@ def kweighted_block_power(audio, coef, lo, hi, norm, layout_tc=True):
 
 
 @_restores_device
-def lufs_norm(audio, coef, lo, hi, block_norm, weights, target_lufs, layout_tc=True, result_device=False):
+def lufs_norm(audio, coef, lo, hi, block_norm, weights, target_lufs, layout_tc=True, result_device=False, want_sumsq=False):
     """Row U in one call (SonicSim_audio.py:68-81): block powers, BS.1770-4 gating, gain and scaling on the device.
     audio (T,), (T,C) / (C,T), or a batch of stems (S,C,T) (channel-first only) with one target per stem.
     Returns (out like audio, loudness, linear gain, sum(out), sum(audio)) -- scalars, or length-S lists for a batch.
     result_device=True (device tensors only): nothing comes back to the host -- returns (out, res) with res a float64 device tensor
-    (S, 4) = {loudness, gain, sum(out), sum(audio)} per stem; the call only enqueues work (a scene generator reads it when it wants)."""
+    (S, 4) = {loudness, gain, sum(out), sum(audio)} per stem; the call only enqueues work (a scene generator reads it when it wants).
+    want_sumsq=True (with result_device): returns (out, res, sumsq) -- sumsq a float64 device tensor (S,) = sum(out[s] ** 2), accumulated by the
+    pass that writes ``out``; ``mix(..., presums=...)`` takes the speakers' and the noise's entries instead of measuring the stems again."""
     lib = _lib.load()
     coef = np.ascontiguousarray(np.asarray(coef, dtype=np.float64).reshape(2, 6))
     lo = np.ascontiguousarray(np.asarray(lo, dtype=np.int64))
@@ -879,10 +893,18 @@ def lufs_norm(audio, coef, lo, hi, block_norm, weights, target_lufs, layout_tc=T
     tg = np.ascontiguousarray(np.asarray(target_lufs, dtype=np.float64).reshape(-1))
     if tg.shape[0] != S:
         raise ValueError("need one target loudness per stem")
+    if want_sumsq and not result_device:
+        raise ValueError("want_sumsq=True is a by-product of the asynchronous form: pass result_device=True")
     if result_device:
         if not dev:
             raise ValueError("result_device=True needs device tensors")
         res_dev = torch.empty((S, 4), dtype=torch.float64, device=a.device)
+        if want_sumsq:
+            sumsq = torch.empty((S,), dtype=torch.float64, device=a.device)
+            _lib.check(lib.ss_lufs_norm_batch_sq_f32(_ptr(a), _ptr(out), T, C, S, coef.ctypes.data_as(_lib.c_f64p), lo.ctypes.data_as(_lib.c_i64p),
+                                                     hi.ctypes.data_as(_lib.c_i64p), nb, float(block_norm), w.ctypes.data_as(_lib.c_f64p),
+                                                     tg.ctypes.data_as(_lib.c_f64p), _ptr(res_dev), _ptr(sumsq), flags | _lib.FLAG_RESULT_DEVICE, stream))
+            return out, res_dev, sumsq
         _lib.check(lib.ss_lufs_norm_batch_f32(_ptr(a), _ptr(out), T, C, S, coef.ctypes.data_as(_lib.c_f64p), lo.ctypes.data_as(_lib.c_i64p),
                                               hi.ctypes.data_as(_lib.c_i64p), nb, float(block_norm), w.ctypes.data_as(_lib.c_f64p),
                                               tg.ctypes.data_as(_lib.c_f64p), _ptr(res_dev), flags | _lib.FLAG_RESULT_DEVICE, stream))

@@ -60,11 +60,16 @@ def make_scene_inputs(device, scene=0, config="cfg2", defer_norm=True) -> SceneI
 def _normalise_and_mix(stack, fs, nstem, sirs, snr, out, sync=True):
     # row U for all stems in one device call (targets drawn in stem order like successive reference calls);
     # (C,T) stems in place of the reference's transposed (T,C)
-    nstack, gains = A.get_lufs_norm_audio_batch(stack, fs, LUFS_TARGETS[:nstem], allow_many_channels=True, sync=sync)
+    presums = None
+    if sync:
+        nstack, gains = A.get_lufs_norm_audio_batch(stack, fs, LUFS_TARGETS[:nstem], allow_many_channels=True, sync=True)
+    else:       # round 5: the energy of every normalised stem rides on the pass that writes it -- the mix does not measure the stems again
+        nstack, gains, sq = A.get_lufs_norm_audio_batch(stack, fs, LUFS_TARGETS[:nstem], allow_many_channels=True, sync=False, want_sumsq=True)
+        presums = (sq[:2], sq[3:4])
     normed = [nstack[j] for j in range(nstem)]
     noise = normed[3][None]                                                      # 2-speaker separation mixture; the reference scales the interferer in place
     mix, _ = mixing.mix_sources(nstack[:2], noise, np.asarray(sirs, dtype=np.float32), float(snr), out=out,      # (:113) -- here the stems stay as
-                                keep_speakers=True)                                                               # normalised (no clone): row M
+                                keep_speakers=True, presums=presums)                                              # normalised (no clone): row M
     return mix, normed, gains
 
 

@@ -172,9 +172,24 @@ class StreamingRenderer:
         if self.engine == "persistent":
             x = ops._dev32(torch.as_tensor(chunk).to(self.rirs.device), "chunk").reshape(-1)
             out = torch.empty((self.C, n), dtype=torch.float32, device=self.rirs.device)
+            if getattr(self, "_broken", False):
+                raise RuntimeError("this StreamingRenderer failed in an earlier push: its history is inconsistent -- open a new one")
             if n:
                 with torch.cuda.device(self.rirs.device):
-                    self._lib.check(self._lib.load().ss_stream_push(self._h, ops._ptr(x), n, ops._ptr(out), self._lib.FLAG_DEVICE_PTR, ops._stream_ptr(x)))
+                    rc = self._lib.load().ss_stream_push(self._h, ops._ptr(x), n, ops._ptr(out), self._lib.FLAG_DEVICE_PTR, ops._stream_ptr(x))
+                if rc != 0:
+                    # a multi-piece push may have enqueued some of its pieces before it failed: the C side's position has then advanced while ours
+                    # has not, and the x-history holds part of this chunk.  Argument errors are detected before anything is enqueued
+                    # (position unchanged: the handle stays usable); anything else poisons the handle.
+                    import ctypes
+                    try:
+                        v = (ctypes.c_int64 * 6)()
+                        same = self._lib.load().ss_stream_info(self._h, v, 6) == 0 and int(v[0]) == self.pos
+                    except Exception:
+                        same = False
+                    if not same:
+                        self._broken = True
+                    self._lib.check(rc)
             self.pos += n
             return out
         is_t = torch.is_tensor(chunk)

@@ -6,7 +6,7 @@ import torch
 from oracle import loudness as OL
 from oracle import mix as OM
 from oracle import rir_synth as OR
-from util import rel_rms
+from util import assert_parity, rel_rms
 
 pytestmark = pytest.mark.gpu
 
@@ -468,3 +468,44 @@ def test_batched_bank_generator_same_values_as_bank_by_bank(gpu):
     p2 = [torch.zeros(1, device=gpu), torch.zeros(1, device=gpu)]
     ops.rir_bank_synth_batch([(d, g, full.rt60, 9), (d, g, full.rt60, 9)], full.L, full.fs, o, p2)
     assert torch.equal(o[0], one) and torch.equal(o[1], one) and torch.equal(p2[0], pk1) and torch.equal(p2[1], pk1)
+
+
+def test_stem_energies_ride_on_the_loudness_pass_and_feed_the_mix(gpu):
+    """Round 5 (rows U + M back to back): ss_lufs_norm_batch_sq_f32 leaves sum(out^2) of every normalised stem on the device and ss_mix_presum_f32
+    mixes from those sums -- two launches instead of five.  The normalised stems and the records are bit-identical to the plain call; the mix is
+    the ordinary mix's up to the last bit of a gain (float64 energies in another association; gate 1e-6 here, 1e-4 north star)."""
+    from sonicsim_amd import SonicSim_audio as A
+    from sonicsim_amd import mixing, ops
+    rng = np.random.default_rng(21)
+    S, C, T = 5, 4, 163840
+    stems = (rng.standard_normal((S, C, T)) * np.array([0.05, 0.02, 0.08, 0.01, 0.03])[:, None, None]).astype(np.float32)
+    d = torch.from_numpy(stems).to(gpu)
+    np.random.seed(7)
+    o1, r1 = A.get_lufs_norm_audio_batch(d, 16000, (-17, -17, -17, -24, -29), allow_many_channels=True, sync=False)
+    np.random.seed(7)
+    o2, r2, sq = A.get_lufs_norm_audio_batch(d, 16000, (-17, -17, -17, -24, -29), allow_many_channels=True, sync=False, want_sumsq=True)
+    assert torch.equal(o1, o2) and torch.equal(r1, r2)
+    want = (o2.double() ** 2).sum(dim=(1, 2))
+    assert torch.allclose(sq, want, rtol=1e-12, atol=0)
+    sirs = np.asarray([2.5], np.float32)
+    for keep in (True, False):
+        a, b = o2[:2].clone(), o2[:2].clone()
+        m_ref, spk_ref = mixing.mix_sources(a, o2[3][None], sirs, 12.0, keep_speakers=keep)
+        m_new, spk_new = mixing.mix_sources(b, o2[3][None], sirs, 12.0, keep_speakers=keep, presums=(sq[:2], sq[3:4]))
+        torch.cuda.synchronize()
+        den = float(m_ref.double().pow(2).mean().sqrt())
+        assert float((m_new.double() - m_ref.double()).pow(2).mean().sqrt()) / den <= 1e-6
+        assert float((spk_new.double() - spk_ref.double()).abs().max()) <= 1e-6 * float(spk_ref.abs().max())
+        if keep:
+            assert torch.equal(b, o2[:2])                    # read-only speakers
+    # against the oracle's mix (the reference's arithmetic, movingdatamodule.py:105-124)
+    from oracle import mix as OM
+    ref_mix = OM.mix(o2[:2].cpu().numpy(), o2[3][None].cpu().numpy(), sirs, 12.0)[0]
+    m_new, _ = mixing.mix_sources(o2[:2].clone(), o2[3][None], sirs, 12.0, keep_speakers=True, presums=(sq[:2], sq[3:4]))
+    assert_parity(m_new.cpu().numpy(), np.asarray(ref_mix), tol=1e-6)
+    # stems that are not a multiple of four samples fall back to the ordinary path (same result as without presums)
+    odd = o2[:, :, :-1].contiguous()
+    sq_odd = (odd.double() ** 2).sum(dim=(1, 2))
+    m1, _ = mixing.mix_sources(odd[:2].clone(), odd[3][None], sirs, 12.0, keep_speakers=True)
+    m2, _ = mixing.mix_sources(odd[:2].clone(), odd[3][None], sirs, 12.0, keep_speakers=True, presums=(sq_odd[:2], sq_odd[3:4]))
+    assert torch.equal(m1, m2)

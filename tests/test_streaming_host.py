@@ -38,3 +38,70 @@ def test_ranges_shards_and_streaming_match_the_whole_render(oracle_ops):
     assert moving.rel_rms(np.concatenate(out, axis=1), ref) < 2e-6
     with pytest.raises(ValueError):
         sr.push(sc.x[:1])
+
+
+def test_failed_push_of_the_persistent_engine_poisons_the_handle():
+    """ADVICE r4 (streaming.py): a push that fails after some of its pieces were enqueued leaves the C side's position ahead of Python's; the
+    handle must refuse further pushes instead of rendering with an inconsistent history.  An error detected before anything was enqueued
+    (position unchanged) leaves it usable.  (CPU: the library is replaced by a stub.)"""
+    import torch
+    from sonicsim_amd import streaming
+
+    class StubLib:
+        SS_EINVAL = -1
+        FLAG_DEVICE_PTR = 1
+
+        def __init__(self):
+            self.pos = 0
+            self.mode = "ok"
+
+        def load(self):
+            return self
+
+        def check(self, rc):
+            if rc == -1:
+                raise ValueError("stub: bad argument")
+            if rc:
+                raise RuntimeError("stub: launch failed")
+
+        def ss_stream_push(self, h, x, n, out, flags, stream):
+            if self.mode == "arg":
+                return -1
+            if self.mode == "midway":
+                self.pos += n // 2               # half of the pieces went out before the failure
+                return -2
+            self.pos += n
+            return 0
+
+        def ss_stream_info(self, h, v, n):
+            v[0] = self.pos
+            return 0
+
+    sr = streaming.StreamingRenderer.__new__(streaming.StreamingRenderer)
+    sr.engine, sr.pos, sr.total, sr.C, sr._h = "persistent", 0, 10_000, 2, object()
+    sr.rirs = torch.zeros((3, 2, 8))
+    sr._lib = StubLib()
+    import contextlib
+    real_device = torch.cuda.device
+    torch.cuda.device = lambda d: contextlib.nullcontext()
+    real_stream = streaming.ops._stream_ptr
+    streaming.ops._stream_ptr = lambda t: None
+    try:
+        x = torch.zeros(1000)
+        assert sr.push(x).shape == (2, 1000) and sr.pos == 1000
+        sr._lib.mode = "arg"
+        with pytest.raises(ValueError):
+            sr.push(x)
+        assert sr.pos == 1000 and not getattr(sr, "_broken", False)
+        sr._lib.mode = "ok"
+        sr.push(x)
+        sr._lib.mode = "midway"
+        with pytest.raises(RuntimeError):
+            sr.push(x)
+        sr._lib.mode = "ok"
+        with pytest.raises(RuntimeError, match="inconsistent"):
+            sr.push(x)
+    finally:
+        torch.cuda.device = real_device
+        streaming.ops._stream_ptr = real_stream
+    sr._h = None
