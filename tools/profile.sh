@@ -9,8 +9,8 @@ export TMPDIR=/tmp
 # round 4: the default bench line now carries secondary legs (other configs, other kernels): the profile is of the HEADLINE leg alone
 # (--no-secondary); PMC_BENCH_ARGS="--config cfg5" PMC_BANK_BYTES=768000000 profiles another render config
 XARGS=${PMC_BENCH_ARGS:-}
-BENCH="python bench.py --no-live-traffic --no-secondary --steps 20 --warmup 5 --cpu-seconds 0 $XARGS"
-BENCH_PMC="env BENCH_PREWARM_MS=0 BENCH_CALIB=1 python bench.py --no-live-traffic --no-secondary --steps 3 --warmup 1 --cpu-seconds 0 $XARGS"     # counters do not need the sustained state
+BENCH="python bench.py --serial --no-live-traffic --no-secondary --steps 20 --warmup 5 --cpu-seconds 0 $XARGS"
+BENCH_PMC="env BENCH_PREWARM_MS=0 BENCH_CALIB=1 python bench.py --serial --no-live-traffic --no-secondary --steps 3 --warmup 1 --cpu-seconds 0 $XARGS"     # counters do not need the sustained state
 [ -n "${PMC_LIGHT:-}" ] && LIGHT=1 || LIGHT=0
 echo "== kernel-trace --stats" 
 timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/stats -o stats -f csv -- $BENCH > $OUT/stats.log 2>&1
