@@ -268,6 +268,9 @@ def _leg_summary(name, leg):
         for k in ("same_bits_as_the_resident_render", "same_bits_as_three_separate_renders"):
             if k in leg:
                 par = "same bits" if leg[k] else "MISMATCH"
+    if par is None and leg.get("scene_launch_same_bits_as_separate_renders") is not None:
+        v = leg["scene_launch_same_bits_as_separate_renders"]
+        par = "same bits" if v is True else ("MISMATCH" if v is False else str(v))
     if par is None and isinstance(leg.get("gather_verification"), dict):
         par = "same bits" if leg["gather_verification"].get("same_bits") else "MISMATCH"
     row["parity"] = _r(par, 3)
@@ -866,6 +869,23 @@ def run_scenes(args, rank, local_rank, world, dev):
         run(n3, None, 60_000)
         torch.cuda.synchronize()
         cfg3 = {"scenes": n3, "ms_per_step": (time.perf_counter() - t3) / n3 * 1e3}
+    # ---- parity of the scene path inside this leg: the LAST scene's first moving stem and first static stem against the separate entry points on
+    #      the same banks (whose own parity against the oracle is the headline's and the test suite's) -- bits, not tolerances
+    scene_bits = None
+    if rank == 0 and not os.environ.get("BENCH_IN_PMC"):
+        try:
+            from sonicsim_amd import ops as _o
+            sp_ = pool[(per_rank - 1) % len(pool)]
+            rend.render(sp_, seed=77_000, sirs=np.asarray([1.0], np.float32), snr=12.0, sync=False)
+            rend._ensure_set(sp_, 0)
+            banks_, peaks_ = rend._provide(sp_, 77_000, 0)
+            xm, _dl, _dg, seg_, _rt = sp_.speakers[0]
+            xs0 = sp_.statics[0][0]
+            a_ = _o.convolve_moving_seg(xm, banks_[0], seg_, bank_peak=peaks_[0])
+            b_ = _o.convolve_fixed(xs0, banks_[3][0])
+            scene_bits = bool(torch.equal(a_, rend.stack[0]) and torch.equal(b_, rend.stack[3]))
+        except Exception as e:                                   # noqa: BLE001 -- informational
+            scene_bits = repr(e)[:80]
     # ---- the gathered scenes are the scenes: rank 0 re-renders a handful of them itself (first / last scene of a few ranks, the ragged last
     #      shard included) from their global index alone and compares bits with what arrived
     verify = None
@@ -1008,6 +1028,7 @@ def run_scenes(args, rank, local_rank, world, dev):
         "cpu_baseline": cpu,
         "gather_verification": verify,
         "cfg3_no_gather": cfg3,
+        "scene_launch_same_bits_as_separate_renders": scene_bits,
     }
 
 
@@ -1313,6 +1334,7 @@ def secondary_legs(args, rank, local_rank, dev, primary):
                         "config": {"workload": f"cfg3: one full SonicSet sample (2 speakers + noise + music, 8-mic, 60 s), {c3['scenes']} scenes back to back, no gather",
                                    **{k: c4["config"][k] for k in ("T", "P", "C", "L", "fs")}},
                         "roofline": {k: v for k, v in c4["roofline"].items() if k not in ("scene",)}, "cpu_baseline": c4.get("cpu_baseline"),
+                        "scene_launch_same_bits_as_separate_renders": c4.get("scene_launch_same_bits_as_separate_renders"),
                         "note": "measured inside the cfg4 leg (same process, same scene pool); the scene launch and its roofline are the cfg4 leg's"}
     return legs
 
