@@ -13,31 +13,34 @@ resident in HBM before the timed region; outputs stay in HBM.  Scenes shard acro
 scaling: every rank renders its own scene each step); for N > 1 every 5th render of every rank travels to rank 0 (RCCL grouped
 point-to-point over xGMI) WHILE the following renders run -- config 4's ratio of one gathered (C, T) payload per five renders.
 
-Rank 0 prints ONE JSON line (contract in the task statement).  `value` is the sustained rate: after an untimed pre-roll (clock ramp-up) the
-MEDIAN of `--windows` (7) windows, each = W warm-up steps + exactly K timed steps between barrier + synchronize, with no HIP events inside
-(an event pair costs 4-5 us per bracketed launch); every window, the clocks / power around it (amdgpu sysfs) and `value_cold` (the same K
-steps straight after the W warm-up steps of the fresh process) are printed too.  `python bench.py --gpus N` without a launcher starts its N
-ranks itself (torch.distributed.run, one process per GPU) and refuses when the node has fewer GPUs.  Extra objects:
-  roofline     -- algorithmic bytes per launch / mean launch duration of the overlap-save kernel, measured live with HIP events on the
-                  kernel's own stream (ss_prof_*) in event windows interleaved with the value windows; min / median / p90 / max of every
-                  timed launch.
-  cpu_baseline -- the oracle's restatement of the reference algorithm (SciPy oaconvolve of EVERY position + gather,
-                  SonicSim_moving.py:86-94) timed on one host core: the WHOLE config when that takes <= ~45 s (config 2: all 200
-                  positions, ~13 s; its output is what `parity_rel_rms_vs_oracle` compares the timed render with), else a bounded sample of the
-                  positions scaled to all of them (config 5).
-  cpu_baseline_all_cores / cpu_smart -- the same algorithm spread over the host cores (oracle/allcores.py; its whole-config output is the
-                  parity reference when the single-core leg is a sample), and the segment-wise reformulation (2 instead of P convolutions
-                  per sample) on one core.
-  secondary    -- (round 4; N = 1, config 2) the other BASELINE.json configurations and the host-pointer path in the SAME line, each a dict with its
-                  own config.workload, ms_per_step, roofline and cpu_baseline: cfg2_end_to_end_host (NumPy / CPU tensors in, CPU tensor out through
-                  SonicSim_moving.interpolate_moving_audio, with the pinned-DMA time of the same bytes measured beside it -- PCIe inclusive, never
-                  `value`), cfg5, cfg4_per_gpu_share (64 full scenes), cfg1, and -- information -- three config-2 renders in ONE launch.
-                  --no-secondary / --legs host,cfg5,cfg4,cfg1,batch select them.
+OUTPUT (round 5).  Rank 0 prints details FIRST -- one `[leg] name {...}` line per secondary leg and one `[detail] {...}` line with everything measured
+(also written to gpurun_out/bench_detail.json) -- and the contract's JSON object as the LAST stdout line, compact: at most 4096 bytes (`compact_line`;
+tests/test_bench_line.py), because the driver parses the tail of stdout (round 4's single 20 KB line overflowed it).  The last line carries metric,
+value, unit, n_gpus, steps, warmup, ms_per_step, config {workload, T, P, C, L, fs, entry_point, streams, distributed}, roofline {bound, achieved, peak,
+frac, frac_events, traffic, algorithmic_bytes_per_launch, avg_launch_ms, kernel, compute.frac}, cpu_baseline {value, cores, kind, seconds_measured,
+sample}, value_cold, ms_per_step_latency, parity_rel_rms_vs_oracle and `secondary`: ONE FLAT ROW per leg (workload, value, unit, ms_per_step,
+roofline_frac, cpu_baseline_value, parity).
+
+`value` is the sustained rate: after an untimed pre-roll (clock ramp-up) the MEDIAN of `--windows` (7) windows, each = W warm-up steps + exactly K timed
+steps between barrier + synchronize, with no HIP events inside (an event pair costs 4-5 us per bracketed launch); `value_cold` = the same K steps straight
+after the W warm-up steps of the fresh process.  Independent renders alternate over three streams (ops.RenderStreams: the library keeps one workspace lane
+per stream), so the next renders' spectra launches run on the compute units a persistent launch frees at its end; `ms_per_step_latency` is the same loop
+on ONE stream (`--serial`), which is also how every profiler pass and event window runs.  `python bench.py --gpus N` without a launcher starts its N ranks
+itself (torch.distributed.run, one process per GPU) and refuses when the node has fewer GPUs.  What the objects mean:
+  roofline     -- algorithmic bytes per launch / average launch duration of the overlap-save kernel.  `frac` quotes THIS run's own `rocprofv3 --kernel-trace
+                  --stats` child pass (one stream, sustained state; csv kept under gpurun_out/bench_trace/); `frac_events` the HIP events on the kernel's own
+                  stream (ss_prof_*) in event windows interleaved with the value windows of this process.
+  cpu_baseline -- the oracle's restatement of the reference algorithm (SciPy oaconvolve of EVERY position + gather, SonicSim_moving.py:86-94) timed on
+                  one host core: the WHOLE config when that takes <= ~45 s (config 2: all 200 positions, ~13 s; its output is what
+                  `parity_rel_rms_vs_oracle` compares the timed render with), else a bounded sample of the positions scaled to all of them (config 5).
+  cpu_baseline_all_cores / cpu_smart -- the same algorithm spread over the host cores (oracle/allcores.py), and the segment-wise reformulation on one core.
+  secondary    -- (N = 1, config 2) cfg2_end_to_end_host (NumPy / CPU tensors in, CPU tensor out through SonicSim_moving.interpolate_moving_audio; roofline
+                  bound = PCIe with the pinned-DMA rate measured beside it -- never `value`), cfg5, cfg4_per_gpu_share (64 full scenes), cfg3 (the same
+                  scenes without the gather), cfg1, and three config-2 renders in ONE launch.  --no-secondary / --legs host,cfg5,cfg4,cfg1,batch select them.
   roofline.compute -- the arithmetic of the planned transforms over the kernel time against the fp32 vector peak (the bound the kernel lives under).
-  roofline.traffic -- HBM-side bytes per launch of the render kernel measured by THIS run (N = 1, default protocol): two more processes of this
-                  script under `rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes, calibrated on kernels of known byte
-                  counts in the same passes; ~4 s per workload); the committed profiles/pmc_summary.json only if rocprofv3 is missing or fails
-                  (`traffic_source` says which); --no-live-traffic skips the passes.
+  roofline.traffic -- HBM-side bytes per launch measured by THIS run: two more child passes under `rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `--pmc
+                  WRITE_SIZE` (separate passes, calibrated on kernels of known byte counts in the same passes); the committed profiles/pmc_summary.json
+                  only if rocprofv3 is missing or fails (`traffic_source` in the detail says which); --no-live-traffic skips the child passes.
 The oracle is used here only as the timed CPU baseline and as the checker.
 """
 import argparse
