@@ -197,6 +197,12 @@ __global__ __launch_bounds__(256) void k_idx_minmax(const int64_t* __restrict__ 
     }
 }
 
+#ifdef SS_DEBUG_CLK
+__device__ unsigned long long g_dbg_clk[8][2][256];
+#define DBG_CLK(kid, which) do { if (threadIdx.x == 0) { const int wg_ = blockIdx.x + gridDim.x * blockIdx.y; if (wg_ < 256) g_dbg_clk[kid][which][wg_] = wall_clock64(); } } while (0)
+#else
+#define DBG_CLK(kid, which) do {} while (0)
+#endif
 // ---------------------------------------------------------------------------------------------
 // Device-side planner of the explicit (idx, w) schedule for the assembly engine (SS_FLAG_ASYNC_PLAN): the task list of plan.h's
 // build_plan + merge_lpt_xcd, produced on the stream from k_idx_minmax's tile bounds -- no copy to the host, no synchronisation.
@@ -269,6 +275,7 @@ __global__ __launch_bounds__(1024) void k_plan_explicit(PlanDevArgs a) {
     __shared__ int oor_tile;               // first tile of THIS call with an index out of range (status[3..4]: per call, not latched)
     const int tid = threadIdx.x, nt = blockDim.x;
     if (tid == 0) oor_tile = INT32_MAX;
+    DBG_CLK(0, 0);
     // round 4: the planner's scratch arrays live in LDS whenever they fit (they do at every BASELINE.json shape: 4 KB at config 2, 17 KB at
     // config 5) -- a dozen dependent phases then cost LDS round trips instead of trips to the L2 (27.5 -> 23.9 us per call, profiles/r04aq: most of
     // the kernel is the phases' own serial work and synchronisations);
@@ -291,11 +298,30 @@ __global__ __launch_bounds__(1024) void k_plan_explicit(PlanDevArgs a) {
     const bool lanes_per_block = fpb >= 2 && fpb <= 64 && (fpb & (fpb - 1)) == 0 && (nt % fpb) == 0;
     if (lanes_per_block) {
         const long long units = (long long)a.nblk * fpb;
-        for (long long base = 0; base < units; base += nt) {
+        // every round's loads are issued before any of them is used: the rounds' trips to the L2 overlap instead of following each other
+        constexpr int PF = 8;
+        int pl[PF], ph[PF];
+        const bool batched = units <= (long long)PF * nt;
+        if (batched) {
+#pragma unroll
+            for (int k = 0; k < PF; ++k) {
+                const long long u = (long long)k * nt + tid;
+                const bool ok = u < units && u < a.nfine;
+                pl[k] = ok ? a.bmin[u] : 0;
+                ph[k] = ok ? a.bmax[u] : 0;
+            }
+        }
+        int round = 0;
+        for (long long base = 0; base < units; base += nt, ++round) {
             const long long u = base + tid;                        // tile u of the launch: block u / fpb (whole groups of fpb lanes stay inside a wave)
             int lo = INT32_MAX, hi = INT32_MIN;
             if (u < units && u < a.nfine) {
-                const int l = a.bmin[u], h = a.bmax[u];
+                int l, h;
+                if (batched) {
+                    l = pl[0]; h = ph[0];
+#pragma unroll
+                    for (int k = 1; k < PF; ++k) if (round == k) { l = pl[k]; h = ph[k]; }
+                } else { l = a.bmin[u]; h = a.bmax[u]; }
                 if (l < 0 || h > a.P - 2) {
                     if (atomicCAS(&a.status[0], 0, 1) == 0) a.status[1] = (int32_t)(u < INT32_MAX ? u : INT32_MAX);
                     atomicMin(&oor_tile, (int)(u < INT32_MAX ? u : INT32_MAX - 1));
@@ -340,12 +366,14 @@ __global__ __launch_bounds__(1024) void k_plan_explicit(PlanDevArgs a) {
     if (tid < 64) gcount[tid] = 0;
     __syncthreads();
     if (tid == 0) { a.status[3] = oor_tile != INT32_MAX ? 1 : 0; a.status[4] = oor_tile != INT32_MAX ? oor_tile : 0; }
+    DBG_CLK(0, 1);
     // ---- 2: first / last block of every row
     for (int j = tid; j < a.nblk; j += nt) {
         const int lo = a.lo[j], hi = a.hi[j];
         for (int r = lo; r <= hi + 1 && r < a.P; ++r) { atomicMin(&a.first[r], j); atomicMax(&a.last[r], j); }
     }
     __syncthreads();
+    DBG_CLK(1, 0);
     // ---- 3: row-tasks per row (runs of consecutive blocks cut into pieces of at most jmax)
     for (int r = tid; r < a.P; r += nt) {
         const int f = ld_agent(&a.first[r]), l = ld_agent(&a.last[r]);
@@ -358,6 +386,7 @@ __global__ __launch_bounds__(1024) void k_plan_explicit(PlanDevArgs a) {
     }
     __syncthreads();
     long long nrow = block_exclusive_scan(a.rcount, a.P, sh);
+    DBG_CLK(1, 1);
     if (tid == 0) a.status[2] = nrow > a.cap_rows ? 1 : 0;      // per call (not latched): the spectra kernel of THIS render fills y with NaN
     if (nrow > a.cap_rows) {
         if (tid == 0 && atomicCAS(&a.status[0], 0, 2) == 0) a.status[1] = (int32_t)(nrow < INT32_MAX ? nrow : INT32_MAX);
@@ -389,13 +418,23 @@ __global__ __launch_bounds__(1024) void k_plan_explicit(PlanDevArgs a) {
         }
     __syncthreads();
     // ---- 5: ranges of equal total cost; counting sort by (range, descending cost) -- O(N + bins)
+    DBG_CLK(2, 0);
     if (tid == 0) { crange[0] = 4095; crange[1] = 0; }
     __syncthreads();
-    for (int i = tid; i < N; i += nt) {
-        const int c = a.rtask[4 * (size_t)i + 3];
-        a.keys[i] = (unsigned long long)c;
-        atomicMin(&crange[0], c);
-        atomicMax(&crange[1], c);
+    {   // (round 5: one pair of LDS atomics per WAVE instead of per row-task -- N threads on two addresses serialise: 6 of the kernel's 24 us)
+        int cmin_ = 4095, cmax_ = 0;
+        for (int i = tid; i < N; i += nt) {
+            const int c = a.rtask[4 * (size_t)i + 3];
+            a.keys[i] = (unsigned long long)c;
+            cmin_ = c < cmin_ ? c : cmin_;
+            cmax_ = c > cmax_ ? c : cmax_;
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            const int l2 = __shfl_xor(cmin_, o), h2 = __shfl_xor(cmax_, o);
+            cmin_ = l2 < cmin_ ? l2 : cmin_;
+            cmax_ = h2 > cmax_ ? h2 : cmax_;
+        }
+        if ((tid & 63) == 0 && cmin_ <= cmax_) { atomicMin(&crange[0], cmin_); atomicMax(&crange[1], cmax_); }
     }
     __syncthreads();
     int groups = a.groups;
@@ -407,6 +446,7 @@ __global__ __launch_bounds__(1024) void k_plan_explicit(PlanDevArgs a) {
     for (int i = tid; i < nbins; i += nt) a.bins[i] = 0;
     __syncthreads();
     const long long total = block_exclusive_scan(a.keys, N, sh);
+    DBG_CLK(2, 1);
     for (int i = tid; i < N; i += nt) {
         const long long acc = (long long)a.keys[i];
         const int c = a.rtask[4 * (size_t)i + 3];
@@ -419,29 +459,44 @@ __global__ __launch_bounds__(1024) void k_plan_explicit(PlanDevArgs a) {
     }
     __syncthreads();
     block_exclusive_scan(a.bins, nbins, sh);             // start of every (range, cost) class in the sorted order
+    DBG_CLK(3, 0);
     // ---- 6: place every row-task (the order inside a class is whatever the atomics give: equal cost, same range), then the
-    //         round-robin position of each of its C tasks
+    //         round-robin position of each of its C tasks.  Round 5: the rank first (one LDS atomic per row-task), then ALL N * C tasks spread
+    //         over the workgroup's threads, each written with ONE 16-byte store (it was N threads writing 4 C dwords each: 7.6 of the 24 us)
+    __shared__ int gstart[65];
     for (int i = tid; i < N; i += nt) {
         const int cls = (int)(a.keys[i] & 0xffffffffu);
         const int rank = atomicAdd(&a.bins[cls], 1);
-        const int g = (int)(a.keys[i] >> 32);
-        int gs = 0;
-        for (int q = 0; q < g; ++q) gs += gcount[q];
-        const int32_t* t = a.rtask + 4 * (size_t)i;
-        const long long e0 = (long long)(rank - gs) * a.C;
-        for (int c = 0; c < a.C; ++c) {
-            const long long e = e0 + c;
+        a.keys[i] = (a.keys[i] & 0xffffffff00000000ull) | (unsigned long long)(unsigned int)rank;
+    }
+    if (tid == 0) {
+        int run = 0;
+        for (int q = 0; q < groups; ++q) { gstart[q] = run; run += gcount[q]; }
+        gstart[groups] = run;
+    }
+    __syncthreads();
+    {
+        const int Cc = a.C;
+        const long long NC = (long long)N * Cc;
+        for (long long e1 = tid; e1 < NC; e1 += nt) {
+            const int i = (int)(e1 / Cc), c = (int)(e1 - (long long)i * Cc);
+            const unsigned long long key = a.keys[i];
+            const int g = (int)(key >> 32), rank = (int)(key & 0xffffffffu);
+            const int32_t* t = a.rtask + 4 * (size_t)i;
+            const long long e = (long long)(rank - gstart[g]) * Cc + c;
             long long pos = 0;
             for (int q = 0; q < groups; ++q) {
-                const long long cq = (long long)gcount[q] * a.C;
+                const long long cq = (long long)gcount[q] * Cc;
                 pos += cq < e ? cq : e;
                 if (q < g && cq > e) ++pos;
             }
-            int32_t* o = a.out + 4 + 4 * (size_t)pos;
-            o[0] = t[0]; o[1] = c; o[2] = t[1] << a.rs; o[3] = t[2];
+            int4 o4;
+            o4.x = t[0]; o4.y = c; o4.z = t[1] << a.rs; o4.w = t[2];
+            *reinterpret_cast<int4*>(a.out + 4 + 4 * (size_t)pos) = o4;
         }
     }
     if (tid == 0) { a.out[0] = N * a.C; a.out[1] = 0; a.out[2] = 0; a.out[3] = 0; }
+    DBG_CLK(3, 1);
     if (tid == 0 && a.status_host) {               // (thread 0 wrote all three words itself)
         a.status_host[0] = a.status[3];
         a.status_host[1] = a.status[4];
@@ -725,12 +780,6 @@ __global__ __launch_bounds__(256) void k_partial_sum4(const float* __restrict__ 
     if (threadIdx.x == 0) partial[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = (sw[0] + sw[1]) + (sw[2] + sw[3]);
 }
 // fixed-order final sum: lane l adds partial[l], partial[l + 64], ... then a butterfly over the 64 lanes (deterministic)
-#ifdef SS_DEBUG_CLK
-__device__ unsigned long long g_dbg_clk[8][2][256];
-#define DBG_CLK(kid, which) do { if (threadIdx.x == 0) { const int wg_ = blockIdx.x + gridDim.x * blockIdx.y; if (wg_ < 256) g_dbg_clk[kid][which][wg_] = wall_clock64(); } } while (0)
-#else
-#define DBG_CLK(kid, which) do {} while (0)
-#endif
 // SS_FLAG_RESULT_DEVICE: {loudness, gain, sum(out), sum(in)} of stem g straight into a caller's device array -- the final additions in
 // k_final_sum's association (64 strided lanes, then a butterfly), so host-finished and device-finished sums are the same bits
 __device__ __forceinline__ double wave_final_sum(const double* __restrict__ partial, int nb, int lane) {
