@@ -145,14 +145,20 @@ class RenderStreams:
         self.outs = []
         return self
 
-    def next(self):
-        """context manager: the torch current stream of this device is the next side stream, ordered behind everything the caller's stream holds now"""
+    def next_stream(self):
+        """the next side stream, ordered behind everything the caller's stream holds now"""
         s = self.side[self.i % self.depth]
         ev = self.ev[self.i % len(self.ev)]
         self.i += 1
         ev.record(self.main)
         s.wait_event(ev)
-        return self.torch.cuda.stream(s)
+        return s
+
+    def next(self):
+        """context manager: the torch current stream of this device is the next side stream (``next_stream``).  Tensors made on the caller's
+        stream and handed to work inside it must outlive that work, or be declared with ``tensor.record_stream(stream)`` (what the render entry
+        points do for their arguments inside a block)"""
+        return self.torch.cuda.stream(self.next_stream())
 
     def join(self):
         """the caller's stream waits for every render issued so far (called by __exit__)"""
@@ -186,7 +192,11 @@ def _overlappable(fn):
             return fn(*a, **k)                   # another device, or the caller already chose a stream itself (RenderStreams.next())
         rs.busy = True
         try:
-            with rs.next():
+            side = rs.next_stream()
+            for v in list(a) + list(k.values()):         # inputs (and a caller's ``out``) live on the caller's stream: tell the caching allocator that the
+                if _is_dev(v):                           # side stream uses them too, or a tensor the caller drops right after the call could be handed out
+                    v.record_stream(side)                # again while the render still reads it
+            with rs.torch.cuda.stream(side):
                 y = fn(*a, **k)
         finally:
             rs.busy = False

@@ -129,3 +129,23 @@ def test_explicit_schedule_and_scene_launch_on_alternating_streams(gpu):
             assert all(torch.equal(a, b_) for a, b_ in zip(r, scene)), k
         else:
             assert torch.equal(r, want), k
+
+
+def test_inputs_dropped_right_after_the_call_inside_an_overlap_block(gpu):
+    """the render entry points declare their device arguments to the side stream (record_stream): a caller may drop an input right after the call
+    inside the block and allocate again on its own stream without the allocator handing the block out while the render still reads it"""
+    from sonicsim_amd import ops
+    x0, b0, s0, _ = _cases(gpu)[0]
+    want = ops.convolve_moving_seg(x0, b0, s0).clone()
+    torch.cuda.synchronize()
+    outs = []
+    with ops.overlap_renders():
+        for rep in range(6):
+            x = x0.clone()
+            bank = b0.clone()
+            outs.append(ops.convolve_moving_seg(x, bank, s0))
+            del x, bank                                                    # back to the caching allocator at once ...
+            junk = torch.full_like(b0, float("nan"))                       # ... and the caller's stream allocates and scribbles right away
+            del junk
+    for y in outs:
+        assert torch.equal(y, want)
