@@ -63,7 +63,8 @@ def test_more_streams_than_lanes_still_correct(gpu):
             got.append(ops.convolve_moving_seg(x, b, s))
             got.append(ops.convolve_fixed(x, b[0]))
     torch.cuda.synchronize()
-    assert ops.workspace_lanes()["takeovers"] > t0
+    if len({st.cuda_stream for st in streams}) > ops.workspace_lanes()["lanes"]:       # (torch hands streams out of a pool: only distinct handles count)
+        assert ops.workspace_lanes()["takeovers"] > t0
     fixed = [ops.convolve_fixed(x, b[0]) for x, b, s, _ in cases]
     for k in range(2 * n):
         assert torch.equal(got[2 * k], want[k % 2]) and torch.equal(got[2 * k + 1], fixed[k % 2]), k
