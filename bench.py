@@ -746,6 +746,7 @@ def run_cfg2(args, rank, local_rank, world, dev):
                    "T": sc.T, "P": sc.P, "C": sc.C, "L": sc.L, "fs": sc.fs,
                    "entry_point": "ss_convolve_moving_seg_f32", "streams": nstreams if overlap else 1, "parallelism": f"scene-sharded x{world}", "distributed": args.dist_info, "task_queue": "dynamic, one per XCD (the default; ss_set_task_queue)",
                    "gather": f"every {ge}th render of every rank to rank 0, overlapped with the next renders" if do_gather else False,
+                   "gathered_bytes_at_root": int((world - 1) * ngath * sc.C * sc.T * 4) if do_gather else 0,      # per timed window (K steps)
                    "value_is": f"sustained: the MEDIAN of {nwin} windows, each = W warm-up steps + exactly K timed steps between barrier + "
                                "synchronize, after an untimed pre-roll (all windows are listed under `windows`; the HIP events behind `roofline` "
                                "sit in separate, interleaved windows of the same K steps); value_cold = K steps right after the W warm-up steps "
