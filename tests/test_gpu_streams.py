@@ -150,3 +150,35 @@ def test_inputs_dropped_right_after_the_call_inside_an_overlap_block(gpu):
             del junk
     for y in outs:
         assert torch.equal(y, want)
+
+
+def test_whole_scene_pipelines_on_two_streams(gpu):
+    """two SceneRenderers, each on its own stream, render scenes alternately with nothing waiting in between: the scene launch, the batched
+    loudness (whose coefficient / bound / weight tables are cached PER LANE by pointer identity) and the mix-from-energies of one stream must
+    never see the other's workspace.  Mixes and loudness records bit for bit those of one renderer on one stream."""
+    from sonicsim_amd import pipeline
+    specs = [pipeline.make_scene_spec(gpu, scene=s, config="tiny") for s in range(4)]
+    order = [(0, 21), (1, 22), (2, 23), (3, 24), (1, 25), (0, 26), (3, 27), (2, 28)]
+
+    def one_stream():
+        r = pipeline.SceneRenderer(specs[0], gpu)
+        outs = []
+        for i, (si, seed) in enumerate(order):
+            np.random.seed(300 + i)
+            mix, rec = r.render(specs[si], seed=seed, sirs=(0.5,), snr=14.0, sync=False)
+            outs.append((mix.clone(), rec.clone()))
+        torch.cuda.synchronize()
+        return outs
+
+    base = one_stream()
+    streams = [torch.cuda.Stream(device=gpu) for _ in range(2)]
+    rends = [pipeline.SceneRenderer(specs[0], gpu) for _ in range(2)]
+    got = []
+    for i, (si, seed) in enumerate(order):
+        np.random.seed(300 + i)
+        with torch.cuda.stream(streams[i % 2]):
+            mix, rec = rends[i % 2].render(specs[si], seed=seed, sirs=(0.5,), snr=14.0, sync=False)
+            got.append((mix, rec))
+    torch.cuda.synchronize()
+    for i, ((m0, r0), (m1, r1)) in enumerate(zip(base, got)):
+        assert torch.equal(m0, m1) and torch.equal(r0, r1), i
