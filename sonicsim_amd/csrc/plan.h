@@ -452,6 +452,48 @@ inline void plan_scene_lpt(const SceneSrc* src, int nsrc, int64_t T, int C, int 
     if (main_out) *main_out = (int32_t)(m * (size_t)groups);
 }
 
+// Rows cut into MANY tasks: transform the row once.  A trajectory of a few points over a long signal -- what SonicSet.py:40 takes from
+// SonicSim_rir.get_nav_idx (SonicSim_rir.py:1064: a navmesh shortest path, a handful to a few dozen points over 60 s) -- makes every filter
+// row span tens of output blocks, i.e. many tasks of <= jmax blocks, and each of them used to stream and forward-transform the whole row
+// again (P = 12 at config-2 shapes: ~11 transforms of every tap; P = 3: ~60).  Rows with at least `min_tasks` tasks (per channel) get a SLOT
+// in a partition-spectra array that a pre-pass fills once (k_row_spectra: [slot][NP][4096] c32 in the transform's slot order) and their
+// tasks are marked  Task.nj = blocks | 0x100 | slot << 9 : the assembly kernel then only loads the row's spectrum per partition and
+// multiply-accumulates (tools/gen_asm/os13.py, HROW).  Any task list of the assembly engine can be post-processed (implicit, explicit,
+// scene); the list's order is untouched.  rows_out[k] = source << 24 | row for slot k * C + chan.  Returns the number of rows marked.
+// `budget_bytes` bounds the spectra array (it should stay cache resident: 2 x the rows' taps), `max_rows` the pre-pass's row table.
+constexpr int32_t TASK_NJ_MASK = 0xff, TASK_SPECTRA_READY = 0x100, TASK_SLOT_SHIFT = 9;
+constexpr int HROW_MAX = 256;
+inline int flag_long_rows(std::vector<Task>& tasks, const int32_t* Ps, int nsrc, int C, int NP, int min_tasks, int64_t budget_bytes,
+                          int max_rows, std::vector<int32_t>& rows_out) {
+    rows_out.clear();
+    if (tasks.empty() || nsrc < 1 || nsrc > 8 || C < 1) return 0;
+    static thread_local std::vector<int32_t> cnt;
+    int32_t off[9];
+    off[0] = 0;
+    for (int s = 0; s < nsrc; ++s) off[s + 1] = off[s] + (Ps[s] > 1 ? Ps[s] : 1);
+    cnt.assign((size_t)off[nsrc], 0);
+    for (const Task& t : tasks)
+        if ((t.chan & 0xffff) == 0) cnt[(size_t)off[t.chan >> 16] + (size_t)t.row]++;
+    const int64_t per_row = (int64_t)C * NP * (int64_t)(sizeof(c32) * B13);
+    int n = 0;
+    for (int s = 0; s < nsrc; ++s)
+        for (int32_t r = 0; r < off[s + 1] - off[s]; ++r) {
+            int32_t& k = cnt[(size_t)off[s] + (size_t)r];
+            if (k >= min_tasks && n < max_rows && (int64_t)(n + 1) * per_row <= budget_bytes && (int64_t)(n + 1) * C < ((int64_t)1 << 22)) {
+                rows_out.push_back((int32_t)(s << 24) | r);
+                k = -(++n);                                   // -(slot row + 1)
+            } else {
+                k = 0;
+            }
+        }
+    if (!n) return 0;
+    for (Task& t : tasks) {
+        const int32_t k = cnt[(size_t)off[t.chan >> 16] + (size_t)t.row];
+        if (k < 0) t.nj = (t.nj & TASK_NJ_MASK) | TASK_SPECTRA_READY | (((-k - 1) * C + (t.chan & 0xffff)) << TASK_SLOT_SHIFT);
+    }
+    return n;
+}
+
 // fixed receiver: one row, every block, store pass only
 inline void build_plan_fixed(int64_t T, int C, int block, int jmax, Plan& plan) {
     plan.tasks[0].clear();

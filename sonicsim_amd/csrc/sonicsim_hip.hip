@@ -87,14 +87,43 @@ template <int ABL = 0> __global__ __launch_bounds__(512, 2) void k_os12(RenderPa
     os12_body<DevEnv, ABL>(env, prm, (int)blockIdx.x, (int)gridDim.x);
 }
 
+// partition spectra of the filter rows that are cut into many tasks (plan.h flag_long_rows): the row is transformed ONCE here, its tasks in
+// k_os13_asm only multiply-accumulate.  Workgroup (partition p, slot = table row * C + channel); layout [slot][NP][4096] c32 in slot order
+// (stream_store_slots = what the render kernel's own forward transform leaves in its pending-spectrum registers).  Reference: the row's
+// convolution, SonicSim_moving.py:86 -- the same taps, transformed by the same geometry-13 transform as the streaming renderer's rows.
+struct HRowArgs {
+    const float* bank[8];     // per source
+    c32* Hs;
+    const c32* consts;        // geometry-13 table
+    int32_t nrows, C, L, NP;
+    int32_t rows[HROW_MAX];   // source << 24 | row
+};
+constexpr int HROW_PPW = 3;      // partitions per workgroup
+__device__ __forceinline__ void row_spectra_wg(DevEnv& env, const HRowArgs& a, int b) {
+    const int npw = (a.NP + HROW_PPW - 1) / HROW_PPW;
+    const int p0 = (b % npw) * HROW_PPW, slot = b / npw;
+    const int e = a.rows[slot / a.C], c = slot % a.C;
+    const float* h = a.bank[e >> 24] + ((int64_t)(e & 0xffffff) * a.C + c) * a.L;
+    row_spectra_body<HROW_PPW>(env, h, a.L, a.NP, p0, a.consts, a.Hs + (int64_t)slot * a.NP * B13);
+}
+static inline int hrow_workgroups(const HRowArgs& a) { return a.nrows > 0 ? a.nrows * a.C * ((a.NP + HROW_PPW - 1) / HROW_PPW) : 0; }
+// stand-alone launch (host-pointer renders: the bank arrives behind the input-spectra kernel); resident banks ride on k_xspec13's launch
+__global__ __launch_bounds__(512, 2) void k_row_spectra(HRowArgs a) {
+    __shared__ __attribute__((aligned(16))) c32 smem[LDSFWD13_C32];
+    DevEnv env{smem};
+    row_spectra_wg(env, a, (int)blockIdx.x);
+}
+
 // input spectra for the assembly / geometry-13 render kernels (no zero spectrum: their descriptors return zeros out of range)
 // counter: task-queue heads of the render kernel that follows -- ncnt words, 64 bytes apart, each set to cnt_init
 __global__ __launch_bounds__(512, 2) void k_xspec13(const float* __restrict__ x, int64_t T, const c32* __restrict__ consts,
                                                     c32* __restrict__ Xs, int M, float* __restrict__ yzero, int64_t nzero,
                                                     int* __restrict__ counter, int ncnt, int cnt_init, const float* __restrict__ xdiv, int rs,
                                                     const uint4* __restrict__ plan_src, uint4* __restrict__ plan_dst, int plan_n16,
-                                                    const int32_t* __restrict__ fail_flag) {
-    __shared__ __attribute__((aligned(16))) c32 smem[LDS13_C32];
+                                                    const int32_t* __restrict__ fail_flag, const HRowArgs hrow, int nrow_wg) {
+    // nrow_wg > 0: the FIRST nrow_wg workgroups form the partition spectra of the rows that are cut into many tasks (k_row_spectra's body: three
+    // transforms each, so they start first); the other M + 1 are the input spectra.  One launch, one boundary (round 6).
+    __shared__ __attribute__((aligned(16))) c32 smem[LDSFWD13_C32];
     DevEnv env{smem};
     if (counter && blockIdx.x == 0 && (int)threadIdx.x < ncnt) counter[16 * threadIdx.x] = cnt_init;
     // the render's plan (segment table + task list, ~31 KB at config 2) sits in pinned host memory; every workgroup moves its slice to
@@ -109,7 +138,8 @@ __global__ __launch_bounds__(512, 2) void k_xspec13(const float* __restrict__ x,
     // nothing -- y is then filled with NaN instead of zeros: the failure cannot pass as valid silence even if nobody polls
     // ss_async_status (word 2 of the status record is written by every planner run; words 0-1 are the latched error)
     const float fill = (fail_flag && fail_flag[2] != 0) ? __builtin_nanf("") : 0.0f;
-    xspec13_body(env, x, T, consts, Xs, (int)blockIdx.x, M, yzero, nzero, xdiv, rs, fill);
+    if ((int)blockIdx.x < nrow_wg) row_spectra_wg(env, hrow, (int)blockIdx.x);
+    else xspec13_body<DevEnv, LdsFwd13>(env, x, T, consts, Xs, (int)blockIdx.x - nrow_wg, M, yzero, nzero, xdiv, rs, fill);
     if (pok) plan_dst[pi] = pv;
     if (plan_src)       // (a plan larger than the grid's 8 KB per workgroup: the remainder in a strided loop)
         for (int i = pi + (int)gridDim.x * 512; i < plan_n16; i += (int)gridDim.x * 512) plan_dst[i] = plan_src[i];
@@ -137,17 +167,19 @@ struct XspecSrcTab {
 };
 __global__ __launch_bounds__(512, 2) void k_xspec13_multi(XspecSrcTab tab, int64_t T, const c32* __restrict__ consts, int M, int64_t nzero,
                                                           int* __restrict__ counter, int ncnt, int cnt_init, const uint4* __restrict__ plan_src,
-                                                          uint4* __restrict__ plan_dst, int plan_n16) {
-    __shared__ __attribute__((aligned(16))) c32 smem[LDS13_C32];
+                                                          uint4* __restrict__ plan_dst, int plan_n16, const HRowArgs hrow, int nrow_wg) {
+    // 1-D grid: nrow_wg row-spectra workgroups (see k_xspec13), then (M + 1) input-spectra workgroups per source
+    __shared__ __attribute__((aligned(16))) c32 smem[LDSFWD13_C32];
     DevEnv env{smem};
-    const int s = (int)blockIdx.y;
-    const int bid = (int)(blockIdx.y * gridDim.x + blockIdx.x), nblk = (int)(gridDim.x * gridDim.y);
+    const int bid = (int)blockIdx.x, nblk = (int)gridDim.x;
+    const int s = bid < nrow_wg ? 0 : (bid - nrow_wg) / (M + 1), m = bid < nrow_wg ? 0 : (bid - nrow_wg) % (M + 1);
     if (counter && bid == 0 && (int)threadIdx.x < ncnt) counter[16 * threadIdx.x] = cnt_init;
     uint4 pv = make_uint4(0, 0, 0, 0);
     const int pi = 4 * (bid + nblk * ((int)threadIdx.x >> 2)) + ((int)threadIdx.x & 3);      // plan staging: see k_xspec13
     const bool pok = plan_src && pi < plan_n16;
     if (pok) pv = plan_src[pi];
-    xspec13_body(env, tab.x[s], T, consts, tab.Xs[s], (int)blockIdx.x, M, tab.y[s], nzero, tab.xdiv[s], 0, 0.0f);
+    if (bid < nrow_wg) row_spectra_wg(env, hrow, bid);
+    else xspec13_body<DevEnv, LdsFwd13>(env, tab.x[s], T, consts, tab.Xs[s], m, M, tab.y[s], nzero, tab.xdiv[s], 0, 0.0f);
     if (pok) plan_dst[pi] = pv;
     if (plan_src)
         for (int i = pi + nblk * 512; i < plan_n16; i += nblk * 512) plan_dst[i] = plan_src[i];
@@ -1686,7 +1718,7 @@ int fail(int code, const char* fmt, ...) {
 
 #include "hostpipe.h"
 
-enum WsSlot { WS_XS, WS_PLAN, WS_BMIN, WS_BMAX, WS_X, WS_BANK, WS_IDX, WS_W, WS_Y, WS_SCR, WS_SCR2, WS_FILT, WS_META, WS_CNT, WS_LUFS, WS_RES, WS_KWP, WS_KWT, WS_GW, WS_DPLAN, WS_DTASKS, WS_K1, WS_SQ, WS_COUNT };
+enum WsSlot { WS_XS, WS_PLAN, WS_BMIN, WS_BMAX, WS_X, WS_BANK, WS_IDX, WS_W, WS_Y, WS_SCR, WS_SCR2, WS_FILT, WS_META, WS_CNT, WS_LUFS, WS_RES, WS_KWP, WS_KWT, WS_GW, WS_DPLAN, WS_DTASKS, WS_K1, WS_SQ, WS_HS, WS_COUNT };
 
 struct Pinned {
     void* host = nullptr;
@@ -1946,7 +1978,9 @@ struct Os13AsmArgs {
     int32_t rs;            // input spectra every 4096 >> rs samples; Task::j0 in those hop units (plan.h row_tasks)
     // ---- multi-source launches (tools/gen_asm/os13.py: ARG_NSRC, SRC_TAB): Task.chan = source << 16 | channel
     int32_t nsrc;          // <= 1: the fields above describe the one source
-    int32_t pad0[31];
+    int32_t pad_a;
+    const void* hspec;     // partition spectra of the rows marked TASK_SPECTRA_READY (k_row_spectra; os13.py: ARG_HSPEC)
+    int32_t pad0[28];
     struct Src {
         const void* bank;
         const void* Xs;
@@ -1957,7 +1991,7 @@ struct Os13AsmArgs {
         int32_t pad[2];
     } src[8];
 };
-static_assert(sizeof(Os13AsmArgs) == 768 && offsetof(Os13AsmArgs, nsrc) == 128 && offsetof(Os13AsmArgs, src) == 256 && sizeof(Os13AsmArgs::Src) == 64,
+static_assert(sizeof(Os13AsmArgs) == 768 && offsetof(Os13AsmArgs, nsrc) == 128 && offsetof(Os13AsmArgs, hspec) == 136 && offsetof(Os13AsmArgs, src) == 256 && sizeof(Os13AsmArgs::Src) == 64,
               "Os13AsmArgs layout");
 
 // The code object sits next to this shared library (built by sonicsim_amd/build.py); a missing file is an error
@@ -1980,6 +2014,42 @@ int load_mod13(Ctx* c, bool dynq = false) {
     if (e != hipSuccess) return fail(SS_EHIP, "hipModuleLoad(%s) failed: %s", path.c_str(), hipGetErrorString(e));
     e = hipModuleGetFunction(&fn, mod, "k_os13_asm");
     if (e != hipSuccess) return fail(SS_EHIP, "hipModuleGetFunction(k_os13_asm) failed: %s", hipGetErrorString(e));
+    return SS_OK;
+}
+
+// Rows cut into many tasks are transformed once (plan.h flag_long_rows): marks the tasks of `tasks`, sizes the spectra array and fills
+// `ha` for the pre-pass.  Policy: automatic = rows of >= 3 tasks while the array stays within 128 MB (it is read once per task: it has to
+// stay in the L2s / the Infinity Cache to pay -- larger sets, e.g. config 5's two-task rows, keep the transforming tasks; LAB round 6);
+// SS_FLAG_ROW_SPECTRA marks every row (tests, measurements), SS_FLAG_NO_ROW_SPECTRA none.
+int hrow_mark(Ctx* c, std::vector<Task>& tasks, const int32_t* Ps, int nsrc, int C, int NPart, uint32_t flags, HRowArgs& ha) {
+    ha.nrows = 0;
+    if (flags & SS_FLAG_NO_ROW_SPECTRA) return SS_OK;
+    static const int hrow_min = knob("SS_HROW_MIN") ? atoi(knob("SS_HROW_MIN")) : 3;
+    static const int64_t hrow_mb = knob("SS_HROW_MB") ? atoll(knob("SS_HROW_MB")) : 128;
+    const bool force = (flags & SS_FLAG_ROW_SPECTRA) != 0;
+    for (int s = 0; s < nsrc; ++s) if (Ps[s] > 0xffffff) return SS_OK;
+    static thread_local std::vector<int32_t> rows;
+    const int n = flag_long_rows(tasks, Ps, nsrc, C, NPart, force ? 1 : hrow_min, force ? ((int64_t)1 << 40) : (hrow_mb << 20), HROW_MAX, rows);
+    if (!n) return SS_OK;
+    int rc = ws_ensure(c, WS_HS, sizeof(c32) * (size_t)B13 * (size_t)NPart * (size_t)C * (size_t)n);
+    if (rc) return rc;
+    ha.nrows = n;
+    memcpy(ha.rows, rows.data(), sizeof(int32_t) * (size_t)n);
+    return SS_OK;
+}
+
+void hrow_fill(Ctx* c, HRowArgs& ha, int C, int L, int NPart) {
+    ha.Hs = (c32*)c->ws[WS_HS];
+    ha.consts = c->consts13;
+    ha.C = C; ha.L = L; ha.NP = NPart;
+}
+
+int hrow_launch(Ctx* c, HRowArgs& ha, int C, int L, int NPart, hipStream_t stream) {
+    if (ha.nrows <= 0) return SS_OK;
+    ProfScope ps(c, stream, 3);
+    hrow_fill(c, ha, C, L, NPart);
+    hipLaunchKernelGGL(k_row_spectra, dim3((unsigned)hrow_workgroups(ha)), dim3(NT13), 0, stream, ha);
+    HIPCHK(hipGetLastError());
     return SS_OK;
 }
 
@@ -2242,6 +2312,14 @@ int render(int mode, const float* x, int64_t T, const float* bank, int32_t P, in
         if (rs)                                     // these planners work on the block grid: the same tasks in hop units
             for (Task& t : c->plan.tasks[0]) t.j0 <<= rs;
     }
+    HRowArgs hrow;
+    memset(&hrow, 0, sizeof(hrow));
+    bool hrow_done = false;
+    if (g14 && !chunked && !dev_plan && rs == 0) {
+        const int32_t Pone = P;
+        if ((rc = hrow_mark(c, c->plan.tasks[0], &Pone, 1, C, NPart, flags, hrow))) return rc;
+        hrow.bank[0] = dbank;
+    }
     const size_t n0 = c->plan.tasks[0].size(), n1 = c->plan.tasks[1].size();
     const size_t seg_bytes = 2 * sizeof(int64_t) * (size_t)P;      // [seg_start P x i64][inv_seg P x f64: 1/len(segment k), IEEE double division]
     const size_t blob = seg_bytes + sizeof(Task) * (n0 + n1);
@@ -2302,13 +2380,17 @@ int render(int mode, const float* x, int64_t T, const float* bank, int32_t P, in
                 qinit = 0;                                   // every task, the first one included, comes from the queue
             }
             if (g13 || g14) {
-                hipLaunchKernelGGL(k_xspec13, dim3(M + 1), dim3(NT13), 0, stream, dx, T, (const c32*)c->consts13, (c32*)c->ws[WS_XS], M,
+                const bool rows_ride = hrow.nrows > 0 && bank_dev;        // a resident bank: its row spectra are formed by this launch's first workgroups
+                if (rows_ride) { hrow_fill(c, hrow, C, L, NPart); }
+                const int nrow_wg = rows_ride ? hrow_workgroups(hrow) : 0;
+                if (rows_ride) hrow_done = true;
+                hipLaunchKernelGGL(k_xspec13, dim3(M + 1 + nrow_wg), dim3(NT13), 0, stream, dx, T, (const c32*)c->consts13, (c32*)c->ws[WS_XS], M,
                                    // a static source on the assembly engine is STORED (one task per channel and output block): no zero fill
                                    (knob("SS_NO_ZFILL") /* (tuning build: results WRONG) */ || (g14 && mode == COEF_FIXED)) ? (float*)nullptr : dy,
                                    (int64_t)C * T, (g13 || qgroups) ? (int*)c->ws[WS_CNT] : (int*)nullptr, g13 ? 1 : qgroups + 1,
                                    g13 ? 0 : qinit, xdiv, rs, xspec_stages_plan ? (const uint4*)pin->host : (const uint4*)nullptr,
                                    xspec_stages_plan ? (uint4*)c->ws[WS_PLAN] : (uint4*)nullptr, xspec_stages_plan ? (int)blob16 : 0,
-                                   dev_plan ? (const int32_t*)c->async_status : (const int32_t*)nullptr);
+                                   dev_plan ? (const int32_t*)c->async_status : (const int32_t*)nullptr, hrow, nrow_wg);
                 if (xspec_stages_plan) {       // the ring slot may be rewritten once the spectra kernel has consumed it
                     HIPCHK(hipEventRecord(pin->ev, stream));
                     pin->pending = true;
@@ -2389,6 +2471,7 @@ int render(int mode, const float* x, int64_t T, const float* bank, int32_t P, in
         HIPCHK(hipStreamWaitEvent(stream, e_up, 0));
         hp.st_chunks = 1;
     }
+    if (!hrow_done && (rc = hrow_launch(c, hrow, C, L, NPart, stream))) return rc;
     for (int parity = 0; parity < 2; ++parity) {
         size_t nt = parity ? n1 : n0;
         if (dev_plan) nt = parity ? 0 : (size_t)c->num_cu;      // the count lives in the list's header: every CU gets a workgroup
@@ -2408,6 +2491,7 @@ int render(int mode, const float* x, int64_t T, const float* bank, int32_t P, in
             a.ntasks = prm.ntasks; a.mode = mode; a.nwg = (int32_t)nt;
             a.consts = c->consts14; a.counter = qgroups ? c->ws[WS_CNT] : nullptr;
             a.idx = didx; a.w = dw;
+            a.hspec = hrow.nrows > 0 ? c->ws[WS_HS] : nullptr;
             a.qgroups = qgroups;
             a.rs = rs | ((qgroups == 8 && qmain > 0 && qmain < (1 << 22) && (size_t)qmain < n0) ? qmain << 8 : 0);   // bits 8..: the queue split
             const char* trace_file = trace_env;
@@ -2546,6 +2630,10 @@ int render_scene(int nsrc, const float* const* xs, int64_t T, const float* const
     static const int plan_tail = knob("SS_PLAN_TAIL") ? atoi(knob("SS_PLAN_TAIL")) : 12;
     plan_scene_lpt(ssrc, nsrc, T, C, B12, JMAX12, NPart, c->plan.tasks[0], 8, c->dynq ? plan_tail : 0, &qmain);
     c->plan.tasks[1].clear();
+    HRowArgs hrow;
+    memset(&hrow, 0, sizeof(hrow));
+    if ((rc = hrow_mark(c, c->plan.tasks[0], Ps, nsrc, C, NPart, flags, hrow))) return rc;      // the static sources' single rows, long rows of few-point paths
+    for (int s = 0; s < nsrc; ++s) hrow.bank[s] = banks[s];
     const size_t n0 = c->plan.tasks[0].size();
     const size_t blob = seg_total + sizeof(Task) * n0, blob16 = (blob + 15) / 16;
     Pinned* pin;
@@ -2579,8 +2667,11 @@ int render_scene(int nsrc, const float* const* xs, int64_t T, const float* const
             tab.Xs[s] = (c32*)((char*)c->ws[WS_XS] + xs_one * (size_t)s);
             tab.y[s] = Ps[s] > 1 ? ys[s] : nullptr;       // static sources are stored by the render kernel, not added onto zeros
         }
-        hipLaunchKernelGGL(k_xspec13_multi, dim3(M + 1, nsrc), dim3(NT13), 0, stream, tab, T, (const c32*)c->consts13, M, (int64_t)C * T,
-                           qgroups ? (int*)c->ws[WS_CNT] : (int*)nullptr, qgroups + 1, 0, (const uint4*)pin->host, (uint4*)c->ws[WS_PLAN], (int)blob16);
+        if (hrow.nrows > 0) hrow_fill(c, hrow, C, L, NPart);
+        const int nrow_wg = hrow_workgroups(hrow);
+        hipLaunchKernelGGL(k_xspec13_multi, dim3((unsigned)(nrow_wg + (M + 1) * nsrc)), dim3(NT13), 0, stream, tab, T, (const c32*)c->consts13, M, (int64_t)C * T,
+                           qgroups ? (int*)c->ws[WS_CNT] : (int*)nullptr, qgroups + 1, 0, (const uint4*)pin->host, (uint4*)c->ws[WS_PLAN], (int)blob16,
+                           hrow, nrow_wg);
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(pin->ev, stream));
         pin->pending = true;
@@ -2590,6 +2681,7 @@ int render_scene(int nsrc, const float* const* xs, int64_t T, const float* const
         ProfScope ps(c, stream, 0);
         Os13AsmArgs a;
         memset(&a, 0, sizeof(a));
+        a.hspec = hrow.nrows > 0 ? c->ws[WS_HS] : nullptr;
         for (int s = 0; s < nsrc; ++s) {
             Os13AsmArgs::Src& e = a.src[s];
             e.bank = banks[s];

@@ -55,31 +55,36 @@ inline bool stream_next_piece(const int64_t* seg_start, int P, int64_t pos, int6
 
 // the forward transform of geometry 13 from a folded window (lo = first half, hi = second half; a filter partition has hi = 0):
 // z[n] = (lo - i hi) exp(-i pi n / 8192), B-point transform, result in slot order.  Twiddles straight from the (L2-resident) table.
-template <class Env> SS_HD void fwd13_lohi(Env& env, const float (&lo)[8], const float (&hi)[8], const c32* consts, c32 (&v)[8]) {
+struct Tw13 {
+    c32 tw1[8], tw2v[7], tw3v[7];
+};
+template <class Env> SS_HD void fwd13_twiddles(Env& env, const c32* consts, Tw13& t) {
     const int tid = env.tid();
-    Lds13 l; l.base = env.lds();
+    const int lane = tid & 63, n4 = lane & 7;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t.tw1[k] = consts[TW1P_13 + k * 512 + tid];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) { t.tw2v[k - 1] = consts[TW2_13 + (k - 1) * 64 + lane]; t.tw3v[k - 1] = consts[TW3_13 + (k - 1) * 8 + n4]; }
+}
+// the four passes on v[n1] = twisted window samples n1 * 512 + tid (see fwd13_lohi); result in slot order
+// (LdsT: where the exchange regions lie -- Lds13, or the compact LdsFwd13 (tvfir13.h) of kernels that only transform)
+template <class Env, class LdsT = Lds13> SS_HD void fwd13_core(Env& env, const Tw13& t, c32 (&v)[8]) {
+    const int tid = env.tid();
+    LdsT l; l.base = env.lds();
     const int wave = tid >> 6, lane = tid & 63;
     const int k2 = lane >> 3, n4 = lane & 7;
-    c32 tw1[8], tw2v[7], tw3v[7];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) tw1[k] = consts[TW1P_13 + k * 512 + tid];
-#pragma unroll
-    for (int k = 1; k < 8; ++k) { tw2v[k - 1] = consts[TW2_13 + (k - 1) * 64 + lane]; tw3v[k - 1] = consts[TW3_13 + (k - 1) * 8 + n4]; }
     c32* Pv = l.priv(wave);
-#pragma unroll
-    for (int n1 = 0; n1 < 8; ++n1)
-        v[n1] = mk(lo[n1] * SS_C16(n1) - hi[n1] * SS_S16(n1), -(lo[n1] * SS_S16(n1)) - hi[n1] * SS_C16(n1));
     dft8f<false>(v);
     c32* C = l.cross(0);
 #pragma unroll
-    for (int k = 0; k < 8; ++k) C[k * 512 + tid] = cmul(v[k], tw1[k]);
+    for (int k = 0; k < 8; ++k) C[k * 512 + tid] = cmul(v[k], t.tw1[k]);
     env.barrier();
 #pragma unroll
     for (int n = 0; n < 8; ++n) v[n] = C[wave * 512 + n * 64 + lane];
     dft8f<false>(v);
     Pv[lane] = v[0];
 #pragma unroll
-    for (int k = 1; k < 8; ++k) Pv[k * 72 + lane] = cmul(v[k], tw2v[k - 1]);
+    for (int k = 1; k < 8; ++k) Pv[k * 72 + lane] = cmul(v[k], t.tw2v[k - 1]);
     env.wave_sync();
 #pragma unroll
     for (int n = 0; n < 8; ++n) v[n] = Pv[k2 * 72 + n * 8 + n4];
@@ -87,12 +92,20 @@ template <class Env> SS_HD void fwd13_lohi(Env& env, const float (&lo)[8], const
     env.wave_sync();
     Pv[(k2 * 8) * 9 + n4] = v[0];
 #pragma unroll
-    for (int k = 1; k < 8; ++k) Pv[(k2 * 8 + k) * 9 + n4] = cmul(v[k], tw3v[k - 1]);
+    for (int k = 1; k < 8; ++k) Pv[(k2 * 8 + k) * 9 + n4] = cmul(v[k], t.tw3v[k - 1]);
     env.wave_sync();
 #pragma unroll
     for (int n = 0; n < 8; ++n) v[n] = Pv[lane * 9 + n];
     dft8f<false>(v);
     env.wave_sync();
+}
+template <class Env> SS_HD void fwd13_lohi(Env& env, const float (&lo)[8], const float (&hi)[8], const c32* consts, c32 (&v)[8]) {
+    Tw13 t;
+    fwd13_twiddles(env, consts, t);
+#pragma unroll
+    for (int n1 = 0; n1 < 8; ++n1)
+        v[n1] = mk(lo[n1] * SS_C16(n1) - hi[n1] * SS_S16(n1), -(lo[n1] * SS_S16(n1)) - hi[n1] * SS_C16(n1));
+    fwd13_core(env, t, v);
 }
 
 SS_HD void stream_store_slots(c32* out, int tid, const c32 (&v)[8]) {
@@ -126,6 +139,33 @@ template <class Env> SS_HD void stream_row_body(Env& env, const StreamDev& a, in
     c32 v[8];
     fwd13_lohi(env, lo, hi, a.consts, v);
     stream_store_slots(a.Hs + (((int64_t)(row & (STREAM_ROW_SLOTS - 1)) * a.C + c) * a.NP + p) * B13, tid, v);
+}
+
+// Partition spectra of one filter row for the render kernel's spectra-ready tasks (plan.h flag_long_rows): PPW consecutive partitions per
+// workgroup -- the taps of all of them are requested up front (one HBM round trip), the twiddles are fetched once.  h = taps of (row, channel),
+// out = the slot's [NP][B13] array.
+template <int PPW, class Env> SS_HD void row_spectra_body(Env& env, const float* h, int L, int NP, int p0, const c32* consts, c32* out) {
+    const int tid = env.tid();
+    float tap[PPW][8];
+#pragma unroll
+    for (int i = 0; i < PPW; ++i)
+#pragma unroll
+        for (int n1 = 0; n1 < 8; ++n1) {
+            const int64_t k = (int64_t)(p0 + i) * B13 + n1 * 512 + tid;
+            tap[i][n1] = (p0 + i < NP && k < L) ? h[k] : 0.0f;
+        }
+    Tw13 t;
+    fwd13_twiddles(env, consts, t);
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+        if (p0 + i >= NP) break;
+        c32 v[8];
+#pragma unroll
+        for (int n1 = 0; n1 < 8; ++n1) v[n1] = mk(tap[i][n1] * SS_C16(n1), -(tap[i][n1] * SS_S16(n1)));
+        fwd13_core<Env, LdsFwd13>(env, t, v);
+        stream_store_slots(out + (int64_t)(p0 + i) * B13, tid, v);
+        env.barrier();                                  // the cross buffer is rewritten by the next partition's first pass
+    }
 }
 
 // one piece of a push, channel c (workgroup c of a grid of C)

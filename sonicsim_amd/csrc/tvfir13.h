@@ -41,6 +41,15 @@ struct Lds13 {
     SS_HD int* mailbox() const { return reinterpret_cast<int*>(base + MISC13_OFF); }
 };
 
+// kernels that only run forward transforms (input spectra, row spectra) need one cross buffer and the wave-private regions: 70 KB,
+// two workgroups per CU
+struct LdsFwd13 {
+    c32* base;
+    SS_HD c32* cross(int) const { return base; }
+    SS_HD c32* priv(int wave) const { return base + 4096 + wave * 576; }
+};
+constexpr int LDSFWD13_C32 = 4096 + 8 * 576;
+
 // ---------------------------------------------------------------------------------------------
 // two packed spectrum bins as loaded (16 bytes per lane)
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -340,7 +349,7 @@ SS_HD void g13_step(Env& env, const Lds13& l, const P& prm, const Task13& tk, St
 // rs > 0: spectra on a grid of B13 >> rs samples for the assembly engine's hop-aligned tasks (plan.h row_tasks): entry m is the
 // window that starts at (m - (2^rs - 1)) * (B13 >> rs) - B13, i.e. the 2^rs - 1 windows that begin before -B13 + hop .. are kept too
 // (they still cover samples of x); rs = 0 is the block grid the other engines use.
-template <class Env> SS_HD void xspec13_body(Env& env, const float* x, int64_t T, const c32* consts, c32* Xs, int m, int M,
+template <class Env, class LdsT = Lds13> SS_HD void xspec13_body(Env& env, const float* x, int64_t T, const c32* consts, c32* Xs, int m, int M,
                                              float* yzero, int64_t nzero, const float* xdiv = nullptr, int rs = 0, float fill = 0.0f) {
     const int tid = env.tid();
     float lo[8], hi[8];
@@ -367,7 +376,7 @@ template <class Env> SS_HD void xspec13_body(Env& env, const float* x, int64_t T
             for (int64_t i = n4 * 4 + tid; i < nzero; i += NT13) yzero[i] = fill;
     }
     if (m >= M) return;              // (there is no zero spectrum any more: the render kernels' descriptors return zeros)
-    Lds13 l; l.base = env.lds();
+    LdsT l; l.base = env.lds();
     const int wave = tid >> 6, lane = tid & 63;
     const int k2 = lane >> 3, n4 = lane & 7;
     // this thread's 22 twiddles straight from the (L2-resident) table into registers: a workgroup forms ONE spectrum, so staging the

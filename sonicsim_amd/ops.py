@@ -17,7 +17,10 @@ from . import _lib
 
 PATHS = {None: 0, "auto": 0, "os": _lib.FLAG_PATH_OS, "direct": _lib.FLAG_PATH_DIRECT,
          "os2048": _lib.FLAG_PATH_OS | _lib.FLAG_GEOM_2048, "os4096": _lib.FLAG_PATH_OS | _lib.FLAG_GEOM_4096,
-         "os13": _lib.FLAG_PATH_OS | _lib.FLAG_GEOM_13, "asm": _lib.FLAG_PATH_OS | _lib.FLAG_GEOM_ASM}
+         "os13": _lib.FLAG_PATH_OS | _lib.FLAG_GEOM_13, "asm": _lib.FLAG_PATH_OS | _lib.FLAG_GEOM_ASM,
+         # the assembly engine with EVERY filter row transformed once by the pre-pass / with none (default: rows cut into >= 3 tasks)
+         "asm+rows": _lib.FLAG_PATH_OS | _lib.FLAG_GEOM_ASM | _lib.FLAG_ROW_SPECTRA,
+         "asm-rows": _lib.FLAG_PATH_OS | _lib.FLAG_GEOM_ASM | _lib.FLAG_NO_ROW_SPECTRA}
 
 
 def _is_torch(a) -> bool:
@@ -513,12 +516,13 @@ def convolve_moving_seg(x, rirs, seg_len, path=None, out=None, bank_peak=None, h
 
 
 @_restores_device
-def convolve_scene(xs, banks, segs, peaks=None, outs=None):
+def convolve_scene(xs, banks, segs, peaks=None, outs=None, row_spectra=None):
     """All renders of one scene in ONE persistent launch (``ss_convolve_scene_f32``; SonicSet.py:61-94 renders its three moving speakers
     and two static sources one after the other).  xs: n dry signals (T,); banks[i]: (P, C, L) for a moving source (segs[i] = its P - 1
     segment lengths, sum T) or (C, L) / (1, C, L) for a static one (segs[i] None); peaks[i]: optional one-element device tensor (deferred
     peak normalisation of that bank); outs: optional n (C, T) float32 device tensors (e.g. rows of a stem stack).  Device tensors only.
-    Returns the list of outputs -- bit-identical to convolve_moving_seg / convolve_fixed called one by one."""
+    row_spectra: None = automatic (static sources and rows cut into >= 3 tasks are transformed once by the pre-pass), True = every row,
+    False = none.  Returns the list of outputs -- bit-identical to convolve_moving_seg / convolve_fixed called one by one with the same choice."""
     import torch
     lib = _lib.load()
     n = len(xs)
@@ -562,7 +566,8 @@ def convolve_scene(xs, banks, segs, peaks=None, outs=None):
     P_arr = (ctypes.c_int32 * n)(*Ps)
     _set_device(xs[0])
     _lib.check(lib.ss_convolve_scene_f32(n, arr(xs), T, arr(bk), P_arr, C, L, seg_arr, arr(pk) if peaks is not None else None, arr(ys),
-                                         _lib.FLAG_DEVICE_PTR, _stream_ptr(xs[0])))
+                                         _lib.FLAG_DEVICE_PTR | (0 if row_spectra is None else _lib.FLAG_ROW_SPECTRA if row_spectra
+                                                                 else _lib.FLAG_NO_ROW_SPECTRA), _stream_ptr(xs[0])))
     return ys
 
 
