@@ -55,6 +55,15 @@ inline bool stream_next_piece(const int64_t* seg_start, int P, int64_t pos, int6
 
 // the forward transform of geometry 13 from a folded window (lo = first half, hi = second half; a filter partition has hi = 0):
 // z[n] = (lo - i hi) exp(-i pi n / 8192), B-point transform, result in slot order.  Twiddles straight from the (L2-resident) table.
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ float ss_mul_rn(float a, float b) {      // a product ROUNDED on its own: the compiler contracts `a * b` (and __fmul_rn(a, b)) with
+    float r;                                                           // a following addition into one FMA
+    asm("v_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+#else
+inline float ss_mul_rn(float a, float b) { volatile float p = a * b; return p; }
+#endif
 struct Tw13 {
     c32 tw1[8], tw2v[7], tw3v[7];
 };
@@ -161,8 +170,9 @@ template <int PPW, class Env> SS_HD void row_spectra_body(Env& env, const float*
         if (p0 + i >= NP) break;
         c32 v[8];
 #pragma unroll
-        for (int n1 = 0; n1 < 8; ++n1) v[n1] = mk(tap[i][n1] * SS_C16(n1), -(tap[i][n1] * SS_S16(n1)));
-        fwd13_core<Env, LdsFwd13>(env, t, v);
+        for (int n1 = 0; n1 < 8; ++n1)      // two ROUNDED products, as the render kernel's own pass 1 forms them (v_mul_f32): left to the compiler they fuse
+            v[n1] = mk(ss_mul_rn(tap[i][n1], SS_C16(n1)), -ss_mul_rn(tap[i][n1], SS_S16(n1)));      // into the first butterfly's additions and the
+        fwd13_core<Env, LdsFwd13>(env, t, v);                                                        // spectra differ from the kernel's in the last bits
         stream_store_slots(out + (int64_t)(p0 + i) * B13, tid, v);
         env.barrier();                                  // the cross buffer is rewritten by the next partition's first pass
     }

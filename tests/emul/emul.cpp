@@ -142,6 +142,67 @@ int emul_plan_scene(const int64_t* segs, const int32_t* Ps, int nsrc, int64_t T,
     return (int)t.size();
 }
 
+// property tests (tests/test_plan_properties.py): the segment planner with EVERY knob the library and its tuning build can turn -- jmax, XCD
+// ranges, workgroup count, hop-unit block starts, tail queue, row pairing, balanced cut -- followed by the long-row marking (flag_long_rows:
+// hrow_min tasks per row, spectra budget in bytes, row-table size).  out = raw tasks (nj with its flag bits), rows_out = the marked rows.
+int emul_plan_prop(const int64_t* seg_len, int P, int C, int L, int jmax, int groups, int nwg, int rs, int tail_pct, int pair_rows, int balanced,
+                   int hrow_min, int64_t hrow_budget, int hrow_max_rows, int32_t* main_out, int32_t* out, int max_tasks, int32_t* rows_out,
+                   int32_t* nrows_out) {
+    std::vector<int64_t> seg_start(P);
+    int64_t s = 0;
+    for (int k = 0; k < P - 1; ++k) { seg_start[k] = s; s += seg_len[k]; }
+    seg_start[P - 1] = s;
+    const int NP = (L + B12 - 1) / B12;
+    std::vector<Task> t;
+    std::vector<int32_t> scratch;
+    int32_t m = -1;
+    const int keep = g_plan_balanced;
+    g_plan_balanced = balanced;
+    plan_seg_lpt(seg_start, P, C, B12, jmax, NP, t, scratch, groups, nwg, rs, tail_pct, &m, pair_rows != 0);
+    g_plan_balanced = keep;
+    if (main_out) *main_out = m;
+    std::vector<int32_t> rows;
+    int nr = 0;
+    if (hrow_min > 0) {
+        const int32_t Pone = P;
+        nr = flag_long_rows(t, &Pone, 1, C, NP, hrow_min, hrow_budget, hrow_max_rows, rows);
+    }
+    if (nrows_out) *nrows_out = nr;
+    for (int i = 0; i < nr && rows_out; ++i) rows_out[i] = rows[(size_t)i];
+    const int n = (int)std::min<size_t>(t.size(), (size_t)max_tasks);
+    for (int i = 0; i < n; ++i) { out[4 * i] = t[i].row; out[4 * i + 1] = t[i].chan; out[4 * i + 2] = t[i].j0; out[4 * i + 3] = t[i].nj; }
+    return (int)t.size();
+}
+
+// the host planner of an EXPLICIT (idx, w) schedule as the library runs it for the assembly engine (sonicsim_hip.hip render(): per-tile min / max of
+// idx, build_plan, merge_lpt_xcd -- the host twin of k_plan_explicit) + the long-row marking
+int emul_plan_explicit(const int64_t* idx, int64_t T, int P, int C, int L, int jmax, int groups, int hrow_min, int64_t hrow_budget, int32_t* out,
+                       int max_tasks, int32_t* nrows_out) {
+    const int64_t nfine = (T + DTILE - 1) / DTILE;
+    std::vector<int32_t> bmin((size_t)nfine), bmax((size_t)nfine);
+    for (int64_t b = 0; b < nfine; ++b) {
+        int64_t lo = INT64_MAX, hi = INT64_MIN;
+        for (int64_t t = b * DTILE; t < std::min<int64_t>(T, (b + 1) * DTILE); ++t) { lo = std::min(lo, idx[t]); hi = std::max(hi, idx[t]); }
+        bmin[(size_t)b] = (int32_t)lo; bmax[(size_t)b] = (int32_t)hi;
+    }
+    const int NP = (L + B12 - 1) / B12;
+    Plan plan;
+    build_plan(bmin, bmax, P, C, B12 / DTILE, jmax, plan);
+    std::vector<Task> t;
+    std::vector<int32_t> scratch;
+    merge_lpt_xcd(plan, NP, groups, t, scratch);
+    std::vector<int32_t> rows;
+    int nr = 0;
+    if (hrow_min > 0) {
+        const int32_t Pone = P;
+        nr = flag_long_rows(t, &Pone, 1, C, NP, hrow_min, hrow_budget, HROW_MAX, rows);
+    }
+    if (nrows_out) *nrows_out = nr;
+    const int n = (int)std::min<size_t>(t.size(), (size_t)max_tasks);
+    for (int i = 0; i < n; ++i) { out[4 * i] = t[i].row; out[4 * i + 1] = t[i].chan; out[4 * i + 2] = t[i].j0; out[4 * i + 3] = t[i].nj; }
+    return (int)t.size();
+}
+
 // planner cross-check: the direct O(P*C) segment planner must emit exactly the tasks of the generic (min/max driven) planner
 // whose row actually owns samples; returns 0 when consistent, otherwise a positive diagnostic code
 int emul_plan_compare(const int64_t* seg_len, int P, int C, int L, int64_t* nfast, int64_t* ngeneric) {
