@@ -78,8 +78,9 @@ int ss_convolve_moving_f32(const float* x, int64_t T, const float* rirs, int32_t
  * code 0 = none, 1 = interp_index out of range (where = first sample of the offending 1024-sample tile), 2 = schedule too
  * irregular for the device planner's task buffer (where = row-tasks needed; nothing was rendered: use the default path). */
 int ss_async_status(int32_t* code, int64_t* where, void* stream);
-/* The outcome of the LAST render on this device if it planned its schedule on the device (SS_FLAG_ASYNC_PLAN honoured; otherwise
- * *out_of_range = -1: that render validated on the host).  Not latched, not cleared: *out_of_range == 1 with the first offending sample tile in *where, *too_irregular != 0 when the schedule did not fit the planner's task buffer (the output is then NaN).  Waits for the
+/* The outcome of the LAST render ON `stream` if it planned its schedule on the device (SS_FLAG_ASYNC_PLAN honoured; otherwise
+ * *out_of_range = -1: that render validated on the host, or the stream never rendered).  The words are kept per stream (in the stream's
+ * workspace lane, round 6): renders enqueued on other streams cannot overwrite them and are not waited for.  Not latched, not cleared: *out_of_range == 1 with the first offending sample tile in *where, *too_irregular != 0 when the schedule did not fit the planner's task buffer (the output is then NaN).  Waits for the
  * stream that render ran on.  `ops.convolve_moving` validates with it: plan + render optimistically, one synchronisation, raise like the
  * reference's fancy index (SonicSim_moving.py:89-90) -- no bounds array travels to the host. */
 int ss_plan_status_last(int32_t* out_of_range, int64_t* where, int32_t* too_irregular, void* stream);

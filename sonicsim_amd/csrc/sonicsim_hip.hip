@@ -259,7 +259,10 @@ struct PlanDevArgs {
     unsigned long long* keys;   // [cap_rows]
     int32_t* bins;     // [groups * 4096] counting-sort bins
     int32_t* out;      // header (16 bytes: ntasks, 0, 0, 0) + Task[cap_rows * C]
-    int32_t* status;   // [0] code (1 = interp_index out of range, 2 = plan capacity exceeded), [1] tile / count, latched
+    int32_t* status;   // [0] code (1 = interp_index out of range, 2 = plan capacity exceeded), [1] tile / count, latched: ONE record per device (atomicCAS)
+    int32_t* call;     // THIS call's verdict, words [2] too irregular, [3] out of range, [4] its tile: a record of the stream's workspace LANE (round 6:
+                       // in the per-device record a planner on another stream could overwrite them between this planner's write and this render's
+                       // spectra kernel reading word 2 -- a failed render zero-filled, a valid one NaN-filled)
     int32_t* status_host;   // pinned host mirror of THIS run's words {out of range, tile, too irregular} (null: nobody asked): the validating call
                             // reads it after its stream synchronisation instead of paying a device-to-host copy of 32 bytes
 };
@@ -397,7 +400,7 @@ __global__ __launch_bounds__(1024) void k_plan_explicit(PlanDevArgs a) {
     for (int r = tid; r < a.P; r += nt) { a.first[r] = INT32_MAX; a.last[r] = -1; }
     if (tid < 64) gcount[tid] = 0;
     __syncthreads();
-    if (tid == 0) { a.status[3] = oor_tile != INT32_MAX ? 1 : 0; a.status[4] = oor_tile != INT32_MAX ? oor_tile : 0; }
+    if (tid == 0) { a.call[3] = oor_tile != INT32_MAX ? 1 : 0; a.call[4] = oor_tile != INT32_MAX ? oor_tile : 0; }
     DBG_CLK(0, 1);
     // ---- 2: first / last block of every row
     for (int j = tid; j < a.nblk; j += nt) {
@@ -419,7 +422,7 @@ __global__ __launch_bounds__(1024) void k_plan_explicit(PlanDevArgs a) {
     __syncthreads();
     long long nrow = block_exclusive_scan(a.rcount, a.P, sh);
     DBG_CLK(1, 1);
-    if (tid == 0) a.status[2] = nrow > a.cap_rows ? 1 : 0;      // per call (not latched): the spectra kernel of THIS render fills y with NaN
+    if (tid == 0) a.call[2] = nrow > a.cap_rows ? 1 : 0;      // per call (not latched): the spectra kernel of THIS render fills y with NaN
     if (nrow > a.cap_rows) {
         if (tid == 0 && atomicCAS(&a.status[0], 0, 2) == 0) a.status[1] = (int32_t)(nrow < INT32_MAX ? nrow : INT32_MAX);
         nrow = 0;                                   // render nothing rather than part of the schedule
@@ -530,9 +533,9 @@ __global__ __launch_bounds__(1024) void k_plan_explicit(PlanDevArgs a) {
     if (tid == 0) { a.out[0] = N * a.C; a.out[1] = 0; a.out[2] = 0; a.out[3] = 0; }
     DBG_CLK(3, 1);
     if (tid == 0 && a.status_host) {               // (thread 0 wrote all three words itself)
-        a.status_host[0] = a.status[3];
-        a.status_host[1] = a.status[4];
-        a.status_host[2] = a.status[2];
+        a.status_host[0] = a.call[3];
+        a.status_host[1] = a.call[4];
+        a.status_host[2] = a.call[2];
         __threadfence_system();
     }
 }
@@ -1718,7 +1721,7 @@ int fail(int code, const char* fmt, ...) {
 
 #include "hostpipe.h"
 
-enum WsSlot { WS_XS, WS_PLAN, WS_BMIN, WS_BMAX, WS_X, WS_BANK, WS_IDX, WS_W, WS_Y, WS_SCR, WS_SCR2, WS_FILT, WS_META, WS_CNT, WS_LUFS, WS_RES, WS_KWP, WS_KWT, WS_GW, WS_DPLAN, WS_DTASKS, WS_K1, WS_SQ, WS_HS, WS_COUNT };
+enum WsSlot { WS_XS, WS_PLAN, WS_BMIN, WS_BMAX, WS_X, WS_BANK, WS_IDX, WS_W, WS_Y, WS_SCR, WS_SCR2, WS_FILT, WS_META, WS_CNT, WS_LUFS, WS_RES, WS_KWP, WS_KWT, WS_GW, WS_DPLAN, WS_DTASKS, WS_K1, WS_SQ, WS_HS, WS_STATUS, WS_COUNT };
 
 struct Pinned {
     void* host = nullptr;
@@ -1761,6 +1764,7 @@ struct Ctx {
         size_t cap[WS_COUNT] = {};
         hipStream_t stream = nullptr;
         bool used = false;
+        bool dev_planned = false;         // this lane's last render planned its schedule on the device (ss_plan_status_last is about the CALLING stream's lane)
         uint64_t tick = 0;
     } lanes[NLANE];
     int cur_lane = 0;
@@ -2198,6 +2202,7 @@ int render(int mode, const float* x, int64_t T, const float* bank, int32_t P, in
     // explicit schedule planned on the device (assembly engine, device pointers): nothing comes back to the host
     const bool dev_plan = mode == COEF_EXPLICIT && g14 && dev && (flags & SS_FLAG_ASYNC_PLAN);
     c->last_dev_planned = dev_plan;
+    c->lanes[c->cur_lane].dev_planned = dev_plan;
     int32_t* dplan_out = nullptr;
     if (dev_plan) {
         const int nblk = (int)((T + BB - 1) / BB);
@@ -2212,8 +2217,9 @@ int render(int mode, const float* x, int64_t T, const float* bank, int32_t P, in
         if ((rc = ws_ensure(c, WS_DTASKS, 16 + sizeof(Task) * (size_t)cap_rows * C))) return rc;
         if (!c->async_status) {
             HIPCHK(hipMalloc((void**)&c->async_status, 32));
-            HIPCHK(hipMemsetAsync(c->async_status, 0, 32, stream));
+            HIPCHK(hipMemset(c->async_status, 0, 32));                 // synchronous: ordered against every lane's stream, once per device
         }
+        if ((rc = ws_ensure(c, WS_STATUS, 32))) return rc;             // this lane's per-call words
         char* base = (char*)c->ws[WS_DPLAN];
         PlanDevArgs pa;
         pa.bmin = (const int32_t*)c->ws[WS_BMIN]; pa.bmax = (const int32_t*)c->ws[WS_BMAX]; pa.nfine = nfine;
@@ -2222,6 +2228,7 @@ int render(int mode, const float* x, int64_t T, const float* bank, int32_t P, in
         pa.rcount = (int32_t*)(base + o_rc); pa.rtask = (int32_t*)(base + o_rt); pa.keys = (unsigned long long*)(base + o_keys); pa.bins = (int32_t*)(base + o_bins);
         pa.out = dplan_out = (int32_t*)c->ws[WS_DTASKS];
         pa.status = c->async_status;
+        pa.call = (int32_t*)c->ws[WS_STATUS];
         pa.status_host = nullptr;
         if (status_out) {
             if (!c->status_pin) HIPCHK(hipHostMalloc((void**)&c->status_pin, 64, hipHostMallocDefault));
@@ -2390,7 +2397,7 @@ int render(int mode, const float* x, int64_t T, const float* bank, int32_t P, in
                                    (int64_t)C * T, (g13 || qgroups) ? (int*)c->ws[WS_CNT] : (int*)nullptr, g13 ? 1 : qgroups + 1,
                                    g13 ? 0 : qinit, xdiv, rs, xspec_stages_plan ? (const uint4*)pin->host : (const uint4*)nullptr,
                                    xspec_stages_plan ? (uint4*)c->ws[WS_PLAN] : (uint4*)nullptr, xspec_stages_plan ? (int)blob16 : 0,
-                                   dev_plan ? (const int32_t*)c->async_status : (const int32_t*)nullptr, hrow, nrow_wg);
+                                   dev_plan ? (const int32_t*)c->ws[WS_STATUS] : (const int32_t*)nullptr, hrow, nrow_wg);
                 if (xspec_stages_plan) {       // the ring slot may be rewritten once the spectra kernel has consumed it
                     HIPCHK(hipEventRecord(pin->ev, stream));
                     pin->pending = true;
@@ -2555,7 +2562,7 @@ int render(int mode, const float* x, int64_t T, const float* bank, int32_t P, in
                 status_out[0] = sp[0]; status_out[1] = (int64_t)sp[1] * DTILE; status_out[2] = sp[2];
             } else {
                 int32_t h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-                HIPCHK(hipMemcpy(h, c->async_status, 32, hipMemcpyDeviceToHost));
+                HIPCHK(hipMemcpy(h, c->ws[WS_STATUS], 32, hipMemcpyDeviceToHost));
                 status_out[0] = h[3]; status_out[1] = (int64_t)h[4] * DTILE; status_out[2] = h[2];
             }
         }
@@ -2600,6 +2607,7 @@ int render_scene(int nsrc, const float* const* xs, int64_t T, const float* const
     if ((rc = stream_enter(c, stream))) return rc;
     if ((rc = load_mod13(c, c->dynq))) return rc;
     c->last_dev_planned = false;
+    c->lanes[c->cur_lane].dev_planned = false;
     const int M = (int)((T + B12 - 1) / B12);
     const int NPart = (L + B12 - 1) / B12;
     // ---- segment tables (host) + task list
@@ -3013,14 +3021,18 @@ int ss_plan_status_last(int32_t* out_of_range, int64_t* where, int32_t* too_irre
     if (out_of_range) *out_of_range = 0;
     if (where) *where = 0;
     if (too_irregular) *too_irregular = 0;
-    if (!c->async_status || !c->last_dev_planned) {      // the last render validated (or had nothing to validate) on the host: -1 = "not device-planned"
+    hipStream_t stream = (hipStream_t)stream_;
+    // the verdict of the last render ON THIS STREAM: its words live in the stream's workspace lane (round 6), so renders pending on other
+    // streams neither have to be waited for nor can they have overwritten them
+    int lane = -1;
+    for (int i = 0; i < Ctx::NLANE; ++i) if (c->lanes[i].used && c->lanes[i].stream == stream) lane = i;
+    void* words = lane < 0 ? nullptr : (lane == c->cur_lane ? c->ws[WS_STATUS] : c->lanes[lane].ws[WS_STATUS]);
+    if (lane < 0 || !c->lanes[lane].dev_planned || !words) {      // that render validated (or had nothing to validate) on the host: -1 = "not device-planned"
         if (out_of_range) *out_of_range = -1;
         return SS_OK;
     }
-    hipStream_t stream = (hipStream_t)stream_;
-    { const int rcl = sync_other_lanes(c, stream); if (rcl) return rcl; }
     int32_t h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    HIPCHK(hipMemcpyAsync(h, c->async_status, 32, hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipMemcpyAsync(h, words, 32, hipMemcpyDeviceToHost, stream));
     HIPCHK(hipStreamSynchronize(stream));
     if (out_of_range) *out_of_range = h[3];
     if (where) *where = (int64_t)h[4] * DTILE;

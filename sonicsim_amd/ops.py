@@ -443,6 +443,21 @@ def async_status(stream_of=None):
     return int(code.value), int(where.value)
 
 
+def plan_status_last(stream_of=None):
+    """(out_of_range, where, too_irregular) of the LAST render on the stream (``stream_of``'s device's current stream, default the current one)
+    if that render planned its schedule on the device (``convolve_moving(validate=False)``), else ``(-1, 0, 0)``.  Not latched, not cleared, kept per
+    stream: renders enqueued on other streams cannot overwrite it (``ss_plan_status_last``).  Synchronises that stream."""
+    lib = _lib.load()
+    oor, where, irr = ctypes.c_int32(0), ctypes.c_int64(0), ctypes.c_int32(0)
+    if stream_of is not None:
+        stream = _stream_ptr(stream_of)
+    else:
+        import torch
+        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _lib.check(lib.ss_plan_status_last(ctypes.byref(oor), ctypes.byref(where), ctypes.byref(irr), stream))
+    return int(oor.value), int(where.value), int(irr.value)
+
+
 def _check_moving_shapes(x, rirs, idx, w):
     if x.ndim != 1:
         raise ValueError(f"source_audio must be 1-D (audio_len,), got shape {tuple(x.shape)}")

@@ -197,3 +197,57 @@ def test_long_signal_uses_the_planner_global_scratch():
     lo = sel.start - L
     ref = O.convolve_moving_receiver(xs[lo:], bank.cpu().numpy(), idx[lo:], w[lo:])[:, L:]
     assert O.rel_rms(y_async[:, sel].cpu().numpy(), ref) <= 1e-4
+
+
+def test_failed_and_valid_renders_interleaved_on_three_streams():
+    """the planner's per-call words (too irregular -> NaN fill, out of range) were ONE record per device while renders on alternating
+    streams no longer serialise: planner B could overwrite them between planner A's write and A's spectra kernel reading the NaN-fill verdict.
+    They now live in the stream's workspace lane.  A too-irregular render (NaN throughout), an out-of-range one and valid ones, enqueued back to
+    back on three streams with nothing waiting in between, many rounds: every output and every stream's own verdict must be the right one."""
+    from oracle import moving as O
+    T, P, C, L = 204800, 200, 1, 5000
+    ops, rng, dev, x, bank = _setup(T, P, C, L, 9)
+    t = np.arange(T)
+    wild = np.where((t // 64) % 2 == 0, (t // 128) % (P - 1), P - 2 - (t // 128) % (P - 1)).astype(np.int64)      # too irregular for the device planner
+    calm = np.minimum(t // 1100, P - 2).astype(np.int64)
+    bad = calm.copy()
+    bad[150000:150010] = P - 1                                                                                   # out of range
+    w = rng.random(T).astype(np.float32)
+    dw = torch.from_numpy(w).to(dev)
+    d_wild, d_calm, d_bad = (torch.from_numpy(a).to(dev) for a in (wild, calm, bad))
+    want = ops.convolve_moving(x, bank, d_calm, dw, path="asm").clone()
+    assert ops.async_status() == (0, 0)
+    streams = [torch.cuda.Stream(device=dev) for _ in range(3)]
+    torch.cuda.synchronize()
+    for rounds in range(6):
+        outs = []
+        order = [(0, d_wild), (1, d_calm), (2, d_bad), (0, d_calm), (1, d_wild), (2, d_calm)] if rounds % 2 == 0 else \
+                [(0, d_calm), (1, d_bad), (2, d_wild), (0, d_wild), (1, d_calm), (2, d_calm)]
+        for k, idx in order:
+            with torch.cuda.stream(streams[k]):
+                outs.append((k, idx, ops.convolve_moving(x, bank, idx, dw, path="asm", validate=False)))
+        verdicts = []
+        for k in range(3):                               # the LAST render of every stream, asked through that stream
+            with torch.cuda.stream(streams[k]):
+                verdicts.append(ops.plan_status_last())
+        torch.cuda.synchronize()
+        for k, idx, y in outs:
+            if idx is d_wild:
+                assert torch.isnan(y).all(), (rounds, k)
+            elif idx is d_calm:
+                assert torch.equal(y, want), (rounds, k)
+            else:
+                assert torch.isfinite(y).all(), (rounds, k)
+        last = {k: idx for k, idx, _ in outs}
+        for k in range(3):
+            oor, where, irr = verdicts[k]
+            if last[k] is d_wild:
+                assert irr != 0, (rounds, k, verdicts[k])
+            elif last[k] is d_bad:
+                assert (oor, where, irr) == (1, (150000 // 1024) * 1024, 0), (rounds, k, verdicts[k])
+            else:
+                assert (oor, irr) == (0, 0), (rounds, k, verdicts[k])
+        code, where = ops.async_status()                 # the latched (first error wins) record: some error of this round, then cleared
+        assert code in (1, 2)
+        assert ops.async_status() == (0, 0)
+    assert ops.plan_status_last(x)[0] in (0, -1)         # the default stream: its own last render (the validating one above), not a side stream's
