@@ -277,6 +277,10 @@ def _leg_summary(name, leg):
     if par is None and isinstance(leg.get("gather_verification"), dict):
         par = "same bits" if leg["gather_verification"].get("same_bits") else "MISMATCH"
     row["parity"] = _r(par, 3)
+    if leg.get("kernel_time_ratio") is not None:      # cfg_real: the render kernel against the transform-per-task form measured in the same call
+        row["kernel_us"] = _r(leg.get("render_kernel_us"), 4)
+        row["kernel_us_before"] = _r((leg.get("before") or {}).get("render_kernel_us"), 4)
+        row["ms_per_step_before"] = _r((leg.get("before") or {}).get("ms_per_step"), 4)
     sc = ((leg.get("roofline") or {}).get("scene") or {})
     if sc.get("frac") is not None:
         row["scene_frac"] = _r(sc["frac"], 4)
@@ -1285,6 +1289,83 @@ def run_batched(args, dev):
             "windows_ms_per_call": [t * 1e3 for t in ts]}
 
 
+def real_segments(P, T, seed):
+    """P - 1 irregular segment lengths summing to T (ratios up to ~6 between neighbours): the spacing of a navmesh shortest path is not uniform"""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    w = rng.uniform(0.3, 1.8, P - 1)
+    seg = np.floor(w / w.sum() * T).astype(np.int64)
+    seg[-1] += T - seg.sum()
+    return seg
+
+
+def run_real(args, dev, P):
+    """cfg_real: config 2's shapes (8 mics, 60 s @ 16 kHz, 48 000 taps) with the trajectories the reference really produces -- SonicSet.py:40 takes
+    its positions from SonicSim_rir.get_nav_idx (:1064), a navmesh shortest path of a handful to a few dozen points, not 200.  A filter row then
+    spans tens of output blocks; until round 6 each of its 4-block tasks streamed and forward-transformed the whole row again.  `before` = the
+    same kernel with the transform-once path switched off (SS_FLAG_NO_ROW_SPECTRA), measured in the same call; both render the same bits."""
+    import numpy as np
+    import torch
+
+    from oracle import moving as O
+    from sonicsim_amd import ops, synth
+    sc = synth.make_scene("cfg2", scene=100 + P, P=P)
+    seg = real_segments(P, sc.T, 100 + P)
+    bank = ops.rir_bank_synth(sc.delay, sc.dgain, sc.L, sc.fs, sc.rt60, sc.bank_seed, device=dev)
+    ops.peak_normalize_(bank)
+    x = torch.from_numpy(sc.x).to(dev)
+    K = 20
+
+    def measure(path):
+        fn = lambda: ops.convolve_moving_seg(x, bank, seg, path=path)
+        for _ in range(5):
+            fn()
+        torch.cuda.synchronize()
+        walls = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            for _ in range(K):
+                fn()
+            torch.cuda.synchronize()
+            walls.append((time.perf_counter() - t0) / K)
+        ops.prof_enable(True)
+        for _ in range(K):
+            fn()
+        torch.cuda.synchronize()
+        k0, ms0 = ops.prof_read(0)
+        k1, ms1 = ops.prof_read(1)
+        ops.prof_enable(False)
+        return {"ms_per_step": sorted(walls)[len(walls) // 2] * 1e3, "render_kernel_us": ms0 / max(k0, 1) * 1e3, "spectra_kernel_us": ms1 / max(k1, 1) * 1e3}
+
+    before = measure("asm-rows")
+    after = measure(None)
+    y = ops.convolve_moving_seg(x, bank, seg)
+    same = bool(torch.equal(y, ops.convolve_moving_seg(x, bank, seg, path="asm-rows")))
+    out = {"config": {"workload": f"cfg_real P={P}: single moving source, 8-mic, 60 s @16 kHz, {P} trajectory points (irregular spacing), 48000-tap RIRs",
+                      "T": sc.T, "P": P, "C": sc.C, "L": sc.L, "fs": sc.fs},
+           "value": sc.T / sc.fs / (after["ms_per_step"] * 1e-3), "unit": "rendered-audio-sec/sec", "ms_per_step": after["ms_per_step"], "steps": K, "dtype": "f32",
+           "render_kernel_us": after["render_kernel_us"], "spectra_kernel_us": after["spectra_kernel_us"],
+           "before": before, "kernel_time_ratio": after["render_kernel_us"] / before["render_kernel_us"],
+           "step_time_ratio": after["ms_per_step"] / before["ms_per_step"], "same_bits_as_before": same,
+           "note": "before = every task transforms its filter row itself (the only form until round 6); the spectra kernel's time includes the row pre-pass "
+                   "that rides on its launch; kernel times by HIP events around the launches"}
+    nbytes = algorithmic_bytes(sc.T, P, sc.C, sc.L)
+    out["roofline"] = {"bound": "hbm", "achieved": nbytes / (after["render_kernel_us"] * 1e-6) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                       "frac": nbytes / (after["render_kernel_us"] * 1e-6) / 1e9 / 8000.0, "traffic": None,
+                       "note": f"{nbytes / 1e6:.1f} algorithmic MB (SURVEY 8d: 4PCL + 16T + 4CT): with few positions the bank is small and the render is bound "
+                               "by its inverse transforms and the spectra traffic from L2, not by HBM"}
+    if args.cpu_seconds > 0:
+        idx, w = O.expand_segments(seg)
+        bank_h = bank.cpu().numpy()
+        t0 = time.perf_counter()
+        yref = O.convolve_moving_receiver(sc.x, bank_h, idx, w, p_chunk=16)
+        dt = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": sc.T / sc.fs / dt, "unit": "rendered-audio-sec/sec", "cores": 1, "kind": "port", "seconds_measured": dt,
+                               "sample": f"the whole config: reference algorithm over all {P} positions x {sc.C} channels, {dt:.2f} s"}
+        out["parity_rel_rms_vs_oracle"] = O.rel_rms(y.cpu().numpy(), yref)
+    return out
+
+
 def secondary_legs(args, rank, local_rank, dev, primary):
     """The other BASELINE.json configurations in the same driver-run line (N = 1): cfg5 (largest single-GPU render), cfg4's per-GPU
     share (64 full scenes), cfg1 (plumbing), and the host-pointer path of cfg2.  Each leg is a dict with its own config.workload,
@@ -1323,8 +1404,10 @@ def secondary_legs(args, rank, local_rank, dev, primary):
         a.cfg2_cpu_seconds = cb.get("seconds_measured") if "whole config" in str(cb.get("sample", "")) else None
         return run_scenes(a, rank, local_rank, 1, dev)
 
-    want = [w.strip() for w in (args.legs or "host,cfg5,cfg4,cfg1,batch").split(",") if w.strip()]
-    table = {"host": ("cfg2_end_to_end_host", lambda: run_hostpath(args, dev, primary.get("cpu_baseline"))), "cfg5": ("cfg5", cfg5), "cfg4": ("cfg4_per_gpu_share", cfg4),
+    want = [w.strip() for w in (args.legs or "host,cfg5,cfg4,cfg1,batch,real").split(",") if w.strip()]
+    if "real" in want:
+        want = [w for w in want if w != "real"] + ["real12", "real3"]
+    table = {"real12": ("cfg_real_P12", lambda: run_real(args, dev, 12)), "real3": ("cfg_real_P3", lambda: run_real(args, dev, 3)), "host": ("cfg2_end_to_end_host", lambda: run_hostpath(args, dev, primary.get("cpu_baseline"))), "cfg5": ("cfg5", cfg5), "cfg4": ("cfg4_per_gpu_share", cfg4),
              "cfg1": ("cfg1", lambda: run_cfg1(args, dev)), "batch": ("cfg2_three_renders_one_launch", lambda: run_batched(args, dev))}
     for w in want:
         if w in table:
@@ -1384,7 +1467,7 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="default run (cfg2, N = 1) without the legs for cfg5 / cfg4 / cfg1 / the host-pointer path")
     ap.add_argument("--scenes", type=int, default=None, help="cfg3 / cfg4: total number of scenes over all ranks (default steps x ranks); need not divide")
     ap.add_argument("--scene-config", default=None, help="cfg3 / cfg4: shapes of a scene's sources (default cfg2; 'tiny' for dry runs)")
-    ap.add_argument("--legs", default=None, help="secondary legs of the default run, comma separated, in this order: host,cfg5,cfg4,cfg1,batch (default: all)")
+    ap.add_argument("--legs", default=None, help="secondary legs of the default run, comma separated, in this order: host,cfg5,cfg4,cfg1,batch,real (default: all)")
     ap.add_argument("--lib", default=os.environ.get("BENCH_LIB"), help="measurement tools: another build of the library (tuning / A-B variants)")
     args = ap.parse_args()
     if args.lib:

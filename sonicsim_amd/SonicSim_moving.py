@@ -80,4 +80,4 @@ def interpolate_moving_audio(source1_audio, ir1_list, receiver_position):
     y = ops.convolve_moving_seg(src[0], bank, counts)
     if isinstance(y, np.ndarray):
         y = torch.from_numpy(y)
-    return y[..., :audio_len]
+    return y if y.shape[-1] == audio_len else y[..., :audio_len]

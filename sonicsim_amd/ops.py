@@ -9,12 +9,14 @@ from __future__ import annotations
 
 import ctypes
 import functools
+import os
 import threading
 
 import numpy as np
 
 from . import _lib
 
+_PendingTensor = None          # torch.Tensor subclass of lazily joined render outputs (built by _pending_cls on first use)
 PATHS = {None: 0, "auto": 0, "os": _lib.FLAG_PATH_OS, "direct": _lib.FLAG_PATH_DIRECT,
          "os2048": _lib.FLAG_PATH_OS | _lib.FLAG_GEOM_2048, "os4096": _lib.FLAG_PATH_OS | _lib.FLAG_GEOM_4096,
          "os13": _lib.FLAG_PATH_OS | _lib.FLAG_GEOM_13, "asm": _lib.FLAG_PATH_OS | _lib.FLAG_GEOM_ASM,
@@ -24,7 +26,7 @@ PATHS = {None: 0, "auto": 0, "os": _lib.FLAG_PATH_OS, "direct": _lib.FLAG_PATH_D
 
 
 def _is_torch(a) -> bool:
-    return type(a).__module__.startswith("torch") and hasattr(a, "data_ptr")
+    return (type(a).__module__.startswith("torch") or (_PendingTensor is not None and isinstance(a, _PendingTensor))) and hasattr(a, "data_ptr")
 
 
 def _is_dev(a) -> bool:
@@ -42,6 +44,7 @@ def _np32(a, name):
 
 def _dev32(a, name):
     import torch
+    a = _resolve(a)
     if a.dtype != torch.float32:
         a = a.to(torch.float32)
     return a.contiguous()
@@ -53,6 +56,7 @@ def _stream_ptr(t):
 
 
 def _ptr(a):
+    a = _resolve(a)
     if _is_torch(a):
         return ctypes.c_void_p(a.data_ptr())
     return ctypes.c_void_p(a.ctypes.data)
@@ -95,8 +99,120 @@ def init(device: int = -1):
 
 
 # ---- independent renders on alternating streams (round 5) -----------------------------------------------------------------------------
-_active_streams = None
 _side_streams = {}
+_rs_tls = threading.local()          # the RenderStreams block a THREAD is inside (a module global routed other threads' renders too)
+_auto = {"on": os.environ.get("SS_OVERLAP", "1") != "0", "depth": 3}
+
+
+def set_overlap(on=True, depth=3):
+    """Implicit overlap of independent renders (round 6, default ON; ``SS_OVERLAP=0`` in the environment or ``set_overlap(False)`` switches it off).
+    A device-tensor render called WITHOUT ``out=`` on the device's DEFAULT stream outside any ``overlap_renders()`` block -- the plain loop SonicSet.py:77-94 runs: five renders
+    per sample, one after the other -- is enqueued on one of ``depth`` alternating side streams (ordered behind everything the caller's stream
+    holds) and returns at once with a tensor that JOINS LAZILY: the first operation that reads or writes its data (any torch function, ``.cpu()``,
+    another entry point of this package) first makes the current stream wait for that render.  Metadata (``shape``, ``dtype``, ``device``, ``size()``)
+    and plain views (basic indexing, ``view``, ``narrow``, ``squeeze`` ...) do not join.  Same bits as the one-stream order.  What cannot be
+    covered: a raw ``data_ptr()`` handed to another library (call ``ops.join(y)`` first, or switch the overlap off)."""
+    _auto["on"] = bool(on)
+    _auto["depth"] = max(1, min(3, int(depth)))
+
+
+def join(*tensors):
+    """make the current stream wait for the renders that produced these tensors (no-op for anything else); returns plain tensors"""
+    out = tuple(_resolve(t) for t in tensors)
+    return out[0] if len(out) == 1 else out
+
+
+def _pending_cls():
+    """torch.Tensor subclass of the lazily joined render outputs (built on first use: importing this module must not import torch)"""
+    global _PendingTensor
+    if _PendingTensor is not None:
+        return _PendingTensor
+    import torch
+    from torch.utils._pytree import tree_map
+    T = torch.Tensor
+    meta = {T.size, T.dim, T.numel, T.stride, T.element_size, T.storage_offset, T.data_ptr, T.is_contiguous, T.nelement, T.ndimension, T.get_device,
+            T.is_floating_point, T.is_complex, T.__len__}
+    for name in ("shape", "dtype", "device", "is_cuda", "layout", "requires_grad", "ndim", "is_leaf", "grad_fn", "names", "is_sparse", "is_quantized", "is_meta", "itemsize", "nbytes"):
+        prop = getattr(T, name, None)
+        if prop is not None and hasattr(prop, "__get__"):
+            meta.add(prop.__get__)
+    views = {T.view, T.narrow, T.select, T.squeeze, T.unsqueeze, T.transpose, T.permute, T.detach, T.view_as, T.expand, T.unflatten, T.t}
+
+    def basic_index(ix):
+        ix = ix if isinstance(ix, tuple) else (ix,)
+        return all(i is None or i is Ellipsis or isinstance(i, (int, slice)) for i in ix)
+
+    class PendingTensor(torch.Tensor):
+        @staticmethod
+        def __new__(cls, base, ev, side):
+            r = torch.Tensor._make_subclass(cls, base, False)
+            r._ss = [ev, side, None]           # the render's completion event, its stream, the stream that has already waited for it
+            return r
+
+        def _ss_plain(self):
+            with torch._C.DisableTorchFunctionSubclass():
+                return self.as_subclass(torch.Tensor)
+
+        def _ss_join(self):
+            """the current stream of the tensor's device waits for the render; returns the plain tensor (shares the storage)"""
+            plain = self._ss_plain()
+            st = self._ss
+            cur = torch.cuda.current_stream(plain.device)
+            if st[2] is None or st[2] != cur:
+                if cur != st[1]:
+                    cur.wait_event(st[0])
+                    plain.record_stream(cur)       # allocated under the side stream, used on this one from here on
+                st[2] = cur
+            return plain
+
+        @classmethod
+        def __torch_function__(cls, func, types, args=(), kwargs=None):
+            kwargs = kwargs or {}
+            first = args[0] if args else None
+            if func in meta and isinstance(first, PendingTensor):
+                with torch._C.DisableTorchFunctionSubclass():
+                    return func(first._ss_plain(), *args[1:], **kwargs)
+            if isinstance(first, PendingTensor) and (func in views or (func is T.__getitem__ and len(args) == 2 and basic_index(args[1]))) and \
+                    not any(isinstance(a, PendingTensor) for a in list(args[1:]) + list(kwargs.values())):
+                with torch._C.DisableTorchFunctionSubclass():
+                    v = func(first._ss_plain(), *args[1:], **kwargs)      # a view of the same storage: still pending, no join
+                if isinstance(v, torch.Tensor) and v.untyped_storage().data_ptr() == first._ss_plain().untyped_storage().data_ptr():
+                    r = PendingTensor(v, first._ss[0], first._ss[1])
+                    r._ss = first._ss                                     # (one join state for the render, shared by its views)
+                    return r
+                return v
+            res = lambda a: a._ss_join() if isinstance(a, PendingTensor) else a
+            args, kwargs = tree_map(res, args), tree_map(res, kwargs)
+            with torch._C.DisableTorchFunctionSubclass():
+                return func(*args, **kwargs)
+
+        def __reduce_ex__(self, proto):
+            return self._ss_join().__reduce_ex__(proto)
+
+    _PendingTensor = PendingTensor
+    return PendingTensor
+
+
+def _resolve(v):
+    """a lazily joined render output -> the plain tensor, ordered on the current stream; anything else unchanged"""
+    if _PendingTensor is not None and isinstance(v, _PendingTensor):
+        return v._ss_join()
+    return v
+
+
+class _AutoStreams:
+    """implicit mode: the state RenderStreams keeps per block, kept per (thread, device) instead"""
+
+    def __init__(self, torch, device):
+        self.torch, self.device = torch, device
+        self.ev_in = [torch.cuda.Event() for _ in range(8)]
+        self.i = 0
+
+    def side(self, depth):
+        pool = _side_streams.setdefault((self.device.type, self.device.index), [])
+        while len(pool) < depth:
+            pool.append(self.torch.cuda.Stream(device=self.device))
+        return pool[:depth]
 
 
 class RenderStreams:
@@ -126,6 +242,8 @@ class RenderStreams:
             raise ValueError("depth must be 1..3 (the library keeps four workspace lanes per device: the caller's stream + three)")
         self.torch = torch
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        if self.device.index is None:              # 'cuda' without an index never compared equal to a tensor's device: overlap was silently off
+            self.device = torch.device("cuda", torch.cuda.current_device())
         self.depth = max(1, int(depth))
         # the side streams of a device are created once and shared by every block: the library keeps ONE workspace lane per stream it has seen
         # (four per device), so fresh streams per block would push live lanes out (each takeover is a stream synchronisation)
@@ -141,10 +259,9 @@ class RenderStreams:
         self._prev = None
 
     def __enter__(self):
-        global _active_streams
         self.main = self.torch.cuda.current_stream(self.device)
-        self._prev = _active_streams
-        _active_streams = self
+        self._prev = getattr(_rs_tls, "active", None)
+        _rs_tls.active = self
         self.outs = []
         return self
 
@@ -172,8 +289,7 @@ class RenderStreams:
         self.outs = []
 
     def __exit__(self, *exc):
-        global _active_streams
-        _active_streams = self._prev
+        _rs_tls.active = self._prev
         self.join()
         return False
 
@@ -184,11 +300,18 @@ def overlap_renders(device=None, depth=3):
 
 
 def _overlappable(fn):
-    """render entry points: inside a RenderStreams block a call on device tensors runs on the next side stream"""
+    """render entry points: inside a RenderStreams block a call on device tensors runs on the next side stream; outside any block (implicit mode,
+    ``set_overlap``) a call without ``out=`` does too and returns a lazily joined tensor"""
     @functools.wraps(fn)
     def wrap(*a, **k):
-        rs = _active_streams
-        if rs is None or rs.busy or not any(_is_dev(v) for v in a[:2]):
+        a = tuple(_resolve(v) for v in a)
+        k = {n: _resolve(v) for n, v in k.items()}
+        rs = getattr(_rs_tls, "active", None)
+        if not any(_is_dev(v) for v in a[:2]):
+            return fn(*a, **k)
+        if rs is None:
+            return _implicit(fn, a, k)
+        if rs.busy:
             return fn(*a, **k)
         t = next(v for v in a[:2] if _is_dev(v))
         if t.device != rs.device or rs.torch.cuda.current_stream(rs.device) != rs.main:
@@ -207,6 +330,45 @@ def _overlappable(fn):
             rs.outs.append(y)
         return y
     return wrap
+
+
+def _implicit(fn, a, k):
+    """implicit overlap (set_overlap): the render on the next side stream, its output a lazily joined tensor"""
+    if not _auto["on"] or k.get("out") is not None or getattr(_rs_tls, "in_auto", False):
+        return fn(*a, **k)
+    import torch
+    t = next(v for v in a[:2] if _is_dev(v))
+    dev = t.device
+    main = torch.cuda.current_stream(dev)
+    key = (dev.type, dev.index)
+    if main != torch.cuda.default_stream(dev):
+        return fn(*a, **k)                               # the caller chose a stream itself (its own pipelines, RenderStreams.next(), SceneGather): its ordering
+    st = getattr(_rs_tls, "auto", None)
+    if st is None:
+        st = _rs_tls.auto = {}
+    au = st.get(key)
+    if au is None:
+        au = st[key] = _AutoStreams(torch, dev)
+    sides = au.side(_auto["depth"])
+    side = sides[au.i % len(sides)]
+    ev = au.ev_in[au.i % len(au.ev_in)]
+    au.i += 1
+    ev.record(main)                                      # the side stream starts behind everything the caller's stream holds now (the inputs)
+    side.wait_event(ev)
+    for v in list(a) + list(k.values()):
+        if _is_dev(v):
+            v.record_stream(side)
+    _rs_tls.in_auto = True
+    try:
+        with torch.cuda.stream(side):
+            y = fn(*a, **k)
+            if not _is_dev(y):
+                return y
+            done = torch.cuda.Event()
+            done.record(side)
+    finally:
+        _rs_tls.in_auto = False
+    return _pending_cls()(y, done, side)
 
 
 _PIN_POOL = {"free": {}, "bytes": 0, "cap": 256 << 20, "on": True}      # leased pinned output buffers (host-pointer renders)
@@ -1021,6 +1183,7 @@ def crop_rms_db(stems, starts, n):
     """compute_mch_rms_dB (movingdatamodule.py:29-32) of crops [start, start + n) of resident stems, all in one launch.
     stems: list of float32 device tensors, each (T,) or (C, T) contiguous, same shape; starts: list of ints.
     Returns a float64 array (len(starts), len(stems)).  Synchronises."""
+    stems = [_resolve(s) for s in stems]
     t0 = stems[0]
     C, T = (1, t0.shape[0]) if t0.ndim == 1 else (t0.shape[0], t0.shape[1])
     ptrs = []
@@ -1060,7 +1223,7 @@ def mix_batch(speaker_crops, noise_crops, n, sirs, snrs, want_gains=False):
                     raise ValueError("stems must be contiguous float32 tensors of one shape on one device")
                 if st < 0 or st + n > T:
                     raise ValueError("crop outside the stem")
-                dst.append(t.data_ptr() + 4 * int(st))
+                dst.append(_resolve(t).data_ptr() + 4 * int(st))
     sirs = np.ascontiguousarray(np.asarray(sirs, dtype=np.float32).reshape(B, max(S - 1, 0)))
     snrs = np.ascontiguousarray(np.asarray(snrs, dtype=np.float32).reshape(B))
     shape = (n,) if mono else (C, n)
@@ -1080,6 +1243,8 @@ def crop_sum(first, second, n):
     """movingdatamodule_remix.py:136-146: ``sum(first crops) + sum(second crops)`` without gains.  first / second: lists of
     (tensor (T,), start) on one device; returns (n,) float32."""
     import torch
+    first = [(_resolve(t), st) for t, st in first]
+    second = [(_resolve(t), st) for t, st in second]
     items = list(first) + list(second)
     if not first or len(items) > 8:
         raise ValueError("1..8 sources in all, at least one in the first group")

@@ -88,4 +88,22 @@ if "--cfg5" in sys.argv:
     n, ms = ops.prof_read(0)
     ops.prof_enable(False)
     res.append(f"cfg5 {dt * 1e3:.3f} ms/render  render kernel {ms / max(n, 1) * 1e3:.0f} us")
+if "--real" in sys.argv:                                 # few-point trajectories at config-2 shapes (bench.py's cfg_real legs)
+    import bench
+    xr = torch.from_numpy(synth.gated_noise(960000, 16000, 1000)).to(dev)
+    for Pn in (12, 3):
+        scr = synth.make_scene("cfg2", scene=100 + Pn, P=Pn)
+        segr = bench.real_segments(Pn, scr.T, 100 + Pn)
+        bankr = ops.rir_bank_synth(scr.delay, scr.dgain, scr.L, scr.fs, scr.rt60, scr.bank_seed, device=dev)
+        for _ in range(5):
+            ops.convolve_moving_seg(xr, bankr, segr)
+        torch.cuda.synchronize()
+        ops.prof_enable(True, every=1)
+        for _ in range(100):
+            ops.convolve_moving_seg(xr, bankr, segr)
+        torch.cuda.synchronize()
+        n, ms = ops.prof_read(0)
+        ops.prof_enable(False)
+        res.append(f"real P={Pn} render kernel {ms / max(n, 1) * 1e3:.1f} us")
+        del bankr
 print(f"[{label}] " + " | ".join(res), flush=True)
