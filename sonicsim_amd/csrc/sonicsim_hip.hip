@@ -303,7 +303,7 @@ __device__ inline long long block_exclusive_scan(T* v, int n, long long* sh /*[1
     return carry;
 }
 
-__global__ __launch_bounds__(1024) void k_plan_explicit(PlanDevArgs a) {
+__device__ __forceinline__ void plan_explicit_body(PlanDevArgs a) {
     __shared__ long long sh[17];
     __shared__ int gcount[64];
     __shared__ int crange[2];
@@ -539,6 +539,70 @@ __global__ __launch_bounds__(1024) void k_plan_explicit(PlanDevArgs a) {
         __threadfence_system();
     }
 }
+__global__ __launch_bounds__(1024) void k_plan_explicit(PlanDevArgs a) { plan_explicit_body(a); }
+
+// Everything an EXPLICIT (idx, w) render needs ahead of its persistent launch, in ONE launch (round 6): the per-tile min / max of idx
+// (workgroups [0, n_mm): FRONT_MMT tiles each), the device planner (workgroup n_mm: it waits for the n_mm arrivals, then runs k_plan_explicit's body),
+// the input spectra + zero fill (the other M + 1 workgroups).  The two planner kernels used to run serially ahead of the spectra kernel, which needs
+// nothing of theirs: 4.5 + 15 us + two boundaries on the critical path of convolve_moving_receiver (SonicSim_moving.py:63-96).  Workgroups are
+// dispatched in index order, so when the planner spins every workgroup it waits for is already resident: no deadlock.  (Two streams instead cost
+// two cross-queue dependencies of ~8 us each: measured slower than the serial form, profiles/r06o.)
+constexpr int FRONT_MMT = 8;
+template <bool PLAN> __global__ __launch_bounds__(512, PLAN ? 1 : 2) void k_front_explicit(const float* __restrict__ x, int64_t T, const c32* __restrict__ consts, c32* __restrict__ Xs, int M,
+                                                           float* __restrict__ yzero, int64_t nzero, int* __restrict__ counter, int ncnt, int cnt_init,
+                                                           const float* __restrict__ xdiv, const int64_t* __restrict__ idx, int32_t* __restrict__ bmin,
+                                                           int32_t* __restrict__ bmax, int n_mm, int* __restrict__ mm_done, PlanDevArgs pa) {
+    const int b = (int)blockIdx.x, tid = (int)threadIdx.x;
+    if (counter && b == 0 && tid < ncnt) counter[16 * tid] = cnt_init;
+    if (b < n_mm) {      // one tile per WAVE (16 samples per lane, all loads in flight at once): FRONT_MMT = 8 tiles per workgroup, one trip to memory
+        const int64_t nfine = (T + DTILE - 1) / DTILE;
+        const int64_t tile = (int64_t)b * FRONT_MMT + (tid >> 6);
+        const int lane = tid & 63;
+        if (tile < nfine) {
+            long long v[DTILE / 64];
+#pragma unroll
+            for (int k = 0; k < DTILE / 64; ++k) {
+                const int64_t t = tile * DTILE + k * 64 + lane;
+                v[k] = t < T ? idx[t] : idx[tile * DTILE];        // (a tile that exists has its first sample)
+            }
+            long long lo = v[0], hi = v[0];
+#pragma unroll
+            for (int k = 1; k < DTILE / 64; ++k) { lo = v[k] < lo ? v[k] : lo; hi = v[k] > hi ? v[k] : hi; }
+            for (int o = 32; o > 0; o >>= 1) {
+                const long long l2 = __shfl_xor(lo, o), h2 = __shfl_xor(hi, o);
+                lo = l2 < lo ? l2 : lo;
+                hi = h2 > hi ? h2 : hi;
+            }
+            if (lane == 0) {
+                const long long big = 0x7fffffffLL;          // clamp into int32 so out-of-range values are still detected
+                bmin[tile] = (int32_t)(lo < -big ? -big : (lo > big ? big : lo));
+                bmax[tile] = (int32_t)(hi < -big ? -big : (hi > big ? big : hi));
+            }
+            if constexpr (PLAN) __threadfence();             // this wave's two stores are visible device-wide before the workgroup's arrival is counted (an
+                                                             // agent-scope release writes the XCD's dirty L2 lines back: with the spectra kernel's 38 MB
+                                                             // of stores in flight every fence costs microseconds -- why the fused form is slower)
+        }
+        if constexpr (PLAN) {
+            __syncthreads();
+            if (tid == 0) __hip_atomic_fetch_add(mm_done, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        return;
+    }
+    if (PLAN && b == n_mm) {
+        if (tid == 0) {
+            while (__hip_atomic_load(mm_done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < n_mm) __builtin_amdgcn_s_sleep(8);
+            __hip_atomic_store(mm_done, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // (the next call on this lane starts from zero)
+        }
+        __syncthreads();
+        __threadfence();
+        if constexpr (PLAN) plan_explicit_body(pa);
+        return;
+    }
+    __shared__ __attribute__((aligned(16))) c32 smem[LDSFWD13_C32];
+    DevEnv env{smem};
+    xspec13_body<DevEnv, LdsFwd13>(env, x, T, consts, Xs, b - n_mm - (PLAN ? 1 : 0), M, yzero, nzero, xdiv, 0, 0.0f);
+}
+
 
 // ---------------------------------------------------------------------------------------------
 // K1: synthetic RIR bank (row R).  Thread per (c,t), sequential AR(1) over positions.
@@ -1765,6 +1829,7 @@ struct Ctx {
         hipStream_t stream = nullptr;
         bool used = false;
         bool dev_planned = false;         // this lane's last render planned its schedule on the device (ss_plan_status_last is about the CALLING stream's lane)
+        bool status_zeroed = false;       // WS_STATUS of this lane has been cleared once (k_front_explicit's arrival counter lives in its word 7)
         uint64_t tick = 0;
     } lanes[NLANE];
     int cur_lane = 0;
@@ -1984,7 +2049,8 @@ struct Os13AsmArgs {
     int32_t nsrc;          // <= 1: the fields above describe the one source
     int32_t pad_a;
     const void* hspec;     // partition spectra of the rows marked TASK_SPECTRA_READY (k_row_spectra; os13.py: ARG_HSPEC)
-    int32_t pad0[28];
+    const void* verdict;   // device-planned schedule: the lane's verdict words (word 2 != 0: nothing was planned -> the kernel fills y with NaN); else null
+    int32_t pad0[26];
     struct Src {
         const void* bank;
         const void* Xs;
@@ -1995,7 +2061,7 @@ struct Os13AsmArgs {
         int32_t pad[2];
     } src[8];
 };
-static_assert(sizeof(Os13AsmArgs) == 768 && offsetof(Os13AsmArgs, nsrc) == 128 && offsetof(Os13AsmArgs, hspec) == 136 && offsetof(Os13AsmArgs, src) == 256 && sizeof(Os13AsmArgs::Src) == 64,
+static_assert(sizeof(Os13AsmArgs) == 768 && offsetof(Os13AsmArgs, nsrc) == 128 && offsetof(Os13AsmArgs, hspec) == 136 && offsetof(Os13AsmArgs, verdict) == 144 && offsetof(Os13AsmArgs, src) == 256 && sizeof(Os13AsmArgs::Src) == 64,
               "Os13AsmArgs layout");
 
 // The code object sits next to this shared library (built by sonicsim_amd/build.py); a missing file is an error
@@ -2192,15 +2258,20 @@ int render(int mode, const float* x, int64_t T, const float* bank, int32_t P, in
         }
         c->seg_start[P - 1] = s;
         if (s != T) return fail(SS_EINVAL, "sum(seg_len) = %lld != T = %lld", (long long)s, (long long)T);
-    } else if (mode == COEF_EXPLICIT) {
-        if ((rc = ws_ensure(c, WS_BMIN, sizeof(int32_t) * nfine))) return rc;
-        if ((rc = ws_ensure(c, WS_BMAX, sizeof(int32_t) * nfine))) return rc;
-        hipLaunchKernelGGL(k_idx_minmax, dim3((unsigned)nfine), dim3(256), 0, stream, didx, T, (int32_t*)c->ws[WS_BMIN],
-                           (int32_t*)c->ws[WS_BMAX]);
-        HIPCHK(hipGetLastError());
     }
     // explicit schedule planned on the device (assembly engine, device pointers): nothing comes back to the host
     const bool dev_plan = mode == COEF_EXPLICIT && g14 && dev && (flags & SS_FLAG_ASYNC_PLAN);
+    if (mode == COEF_EXPLICIT) {
+        if ((rc = ws_ensure(c, WS_BMIN, sizeof(int32_t) * nfine))) return rc;
+        if ((rc = ws_ensure(c, WS_BMAX, sizeof(int32_t) * nfine))) return rc;
+        if (!dev_plan) {       // (planned on the device: the tile bounds are formed by the first workgroups of k_front_explicit, below)
+            hipLaunchKernelGGL(k_idx_minmax, dim3((unsigned)nfine), dim3(256), 0, stream, didx, T, (int32_t*)c->ws[WS_BMIN],
+                               (int32_t*)c->ws[WS_BMAX]);
+            HIPCHK(hipGetLastError());
+        }
+    }
+    PlanDevArgs pa;
+    memset(&pa, 0, sizeof(pa));
     c->last_dev_planned = dev_plan;
     c->lanes[c->cur_lane].dev_planned = dev_plan;
     int32_t* dplan_out = nullptr;
@@ -2221,7 +2292,6 @@ int render(int mode, const float* x, int64_t T, const float* bank, int32_t P, in
         }
         if ((rc = ws_ensure(c, WS_STATUS, 32))) return rc;             // this lane's per-call words
         char* base = (char*)c->ws[WS_DPLAN];
-        PlanDevArgs pa;
         pa.bmin = (const int32_t*)c->ws[WS_BMIN]; pa.bmax = (const int32_t*)c->ws[WS_BMAX]; pa.nfine = nfine;
         pa.fine_per_block = BB / DTILE; pa.nblk = nblk; pa.P = P; pa.C = C; pa.jmax = JM; pa.NP = NPart; pa.groups = 8; pa.cap_rows = cap_rows; pa.rs = rs;
         pa.lo = (int32_t*)(base + o_lo); pa.hi = (int32_t*)(base + o_hi); pa.first = (int32_t*)(base + o_first); pa.last = (int32_t*)(base + o_last);
@@ -2237,8 +2307,10 @@ int render(int mode, const float* x, int64_t T, const float* bank, int32_t P, in
             HIPCHK(hipHostGetDevicePointer(&dp, c->status_pin, 0));
             pa.status_host = (int32_t*)dp;
         }
-        hipLaunchKernelGGL(k_plan_explicit, dim3(1), dim3(1024), 0, stream, pa);
-        HIPCHK(hipGetLastError());
+        if (!c->ws[WS_STATUS] || !c->lanes[c->cur_lane].status_zeroed) {      // the arrival counter of k_front_explicit (word 7 of the lane's record) starts at zero
+            HIPCHK(hipMemsetAsync(c->ws[WS_STATUS], 0, 32, stream));
+            c->lanes[c->cur_lane].status_zeroed = true;
+        }
         c->plan.tasks[0].clear();
         c->plan.tasks[1].clear();
     } else if (mode == COEF_EXPLICIT) {
@@ -2387,6 +2459,22 @@ int render(int mode, const float* x, int64_t T, const float* bank, int32_t P, in
                 qinit = 0;                                   // every task, the first one included, comes from the queue
             }
             if (g13 || g14) {
+                if (dev_plan) {
+                    const int n_mm = (int)((nfine + FRONT_MMT - 1) / FRONT_MMT);
+                    static const int front_fused = knob("SS_FRONT_FUSED") ? atoi(knob("SS_FRONT_FUSED")) : 0;
+                    if (front_fused) {        // (tuning build: the planner as one more workgroup of this launch -- measured SLOWER, LAB round 6)
+                        hipLaunchKernelGGL(k_front_explicit<true>, dim3((unsigned)(n_mm + 1 + M + 1)), dim3(NT13), 0, stream, dx, T, (const c32*)c->consts13, (c32*)c->ws[WS_XS], M,
+                                           dy, (int64_t)C * T, qgroups ? (int*)c->ws[WS_CNT] : (int*)nullptr, qgroups + 1, qinit, xdiv, didx,
+                                           (int32_t*)c->ws[WS_BMIN], (int32_t*)c->ws[WS_BMAX], n_mm, (int*)c->ws[WS_STATUS] + 7, pa);
+                    } else {
+                        // the tile bounds ride on the input-spectra launch (its first n_mm workgroups: one wave per tile); the planner follows as its
+                        // own one-workgroup launch of 1024 threads -- one kernel and one boundary less than k_idx_minmax + k_plan_explicit + k_xspec13
+                        hipLaunchKernelGGL(k_front_explicit<false>, dim3((unsigned)(n_mm + M + 1)), dim3(NT13), 0, stream, dx, T, (const c32*)c->consts13, (c32*)c->ws[WS_XS], M,
+                                           dy, (int64_t)C * T, qgroups ? (int*)c->ws[WS_CNT] : (int*)nullptr, qgroups + 1, qinit, xdiv, didx,
+                                           (int32_t*)c->ws[WS_BMIN], (int32_t*)c->ws[WS_BMAX], n_mm, (int*)c->ws[WS_STATUS] + 7, pa);
+                        hipLaunchKernelGGL(k_plan_explicit, dim3(1), dim3(1024), 0, stream, pa);
+                    }
+                } else {
                 const bool rows_ride = hrow.nrows > 0 && bank_dev;        // a resident bank: its row spectra are formed by this launch's first workgroups
                 if (rows_ride) { hrow_fill(c, hrow, C, L, NPart); }
                 const int nrow_wg = rows_ride ? hrow_workgroups(hrow) : 0;
@@ -2397,7 +2485,8 @@ int render(int mode, const float* x, int64_t T, const float* bank, int32_t P, in
                                    (int64_t)C * T, (g13 || qgroups) ? (int*)c->ws[WS_CNT] : (int*)nullptr, g13 ? 1 : qgroups + 1,
                                    g13 ? 0 : qinit, xdiv, rs, xspec_stages_plan ? (const uint4*)pin->host : (const uint4*)nullptr,
                                    xspec_stages_plan ? (uint4*)c->ws[WS_PLAN] : (uint4*)nullptr, xspec_stages_plan ? (int)blob16 : 0,
-                                   dev_plan ? (const int32_t*)c->ws[WS_STATUS] : (const int32_t*)nullptr, hrow, nrow_wg);
+                                   (const int32_t*)nullptr /* (the NaN fill on a failed plan moved into the render kernel's prologue) */, hrow, nrow_wg);
+                }
                 if (xspec_stages_plan) {       // the ring slot may be rewritten once the spectra kernel has consumed it
                     HIPCHK(hipEventRecord(pin->ev, stream));
                     pin->pending = true;
@@ -2499,6 +2588,7 @@ int render(int mode, const float* x, int64_t T, const float* bank, int32_t P, in
             a.consts = c->consts14; a.counter = qgroups ? c->ws[WS_CNT] : nullptr;
             a.idx = didx; a.w = dw;
             a.hspec = hrow.nrows > 0 ? c->ws[WS_HS] : nullptr;
+            a.verdict = dev_plan ? c->ws[WS_STATUS] : nullptr;
             a.qgroups = qgroups;
             a.rs = rs | ((qgroups == 8 && qmain > 0 && qmain < (1 << 22) && (size_t)qmain < n0) ? qmain << 8 : 0);   // bits 8..: the queue split
             const char* trace_file = trace_env;
