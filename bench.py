@@ -551,7 +551,7 @@ def run_cfg2(args, rank, local_rank, world, dev):
     ngath = args.steps // ge if do_gather else 0
 
     def make_gather():
-        return parallel.SceneGather(world * ngath, (sc.C, sc.T), device=dev) if ngath else None
+        return parallel.make_gather(args.gather, world * ngath, (sc.C, sc.T), device=dev) if ngath else None
 
     def run_steps(k, sg=None, serial=False):
         """k renders; with a SceneGather every ge-th render lands in its slot and travels to rank 0 while the next renders run"""
@@ -574,8 +574,11 @@ def run_cfg2(args, rank, local_rank, world, dev):
     if world > 1:
         dist.barrier()
         if do_gather:                  # untimed: RCCL builds its point-to-point channels on first use
-            run_steps(ge, parallel.SceneGather(world, (sc.C, sc.T), device=dev))
+            g0 = parallel.make_gather(args.gather, world, (sc.C, sc.T), device=dev)
+            run_steps(ge, g0)
             torch.cuda.synchronize()
+            if hasattr(g0, "close"):
+                g0.close()
 
     def timed(k, serial=False):
         sg = make_gather()
@@ -588,6 +591,8 @@ def run_cfg2(args, rank, local_rank, world, dev):
         if world > 1:
             dist.barrier()
         dt = time.perf_counter() - t0
+        if hasattr(sg, "close"):
+            sg.close()                         # (untimed: the IPC gather's array goes back; collective, like its creation)
         return parallel.barrier_max_seconds(dt, device=dev), y
 
     # ---- cold: W warm-up steps of a fresh process, then K timed steps
@@ -749,7 +754,7 @@ def run_cfg2(args, rank, local_rank, world, dev):
                                f"{sc.P} trajectory points, {sc.L}-tap RIRs (T={sc.T})",
                    "T": sc.T, "P": sc.P, "C": sc.C, "L": sc.L, "fs": sc.fs,
                    "entry_point": "ss_convolve_moving_seg_f32", "streams": nstreams if overlap else 1, "parallelism": f"scene-sharded x{world}", "distributed": args.dist_info, "task_queue": "dynamic, one per XCD (the default; ss_set_task_queue)",
-                   "gather": f"every {ge}th render of every rank to rank 0, overlapped with the next renders" if do_gather else False,
+                   "gather": f"[{args.gather}] every {ge}th render of every rank to rank 0, overlapped with the next renders" if do_gather else False,
                    "gathered_bytes_at_root": int((world - 1) * ngath * sc.C * sc.T * 4) if do_gather else 0,      # per timed window (K steps)
                    "value_is": f"sustained: the MEDIAN of {nwin} windows, each = W warm-up steps + exactly K timed steps between barrier + "
                                "synchronize, after an untimed pre-roll (all windows are listed under `windows`; the HIP events behind `roofline` "
@@ -856,9 +861,13 @@ def run_scenes(args, rank, local_rank, world, dev):
         del calib
         torch.cuda.synchronize()
     lo = parallel.shard_range(total, rank, world)[0] if total else 0
-    run(max(1, args.warmup), parallel.SceneGather(max(1, args.warmup) * world, (pool[0].C, pool[0].T), device=dev) if gather else None, 10_000_000)
+    gw = parallel.make_gather(args.gather, max(1, args.warmup) * world, (pool[0].C, pool[0].T), device=dev) if gather else None
+    run(max(1, args.warmup), gw, 10_000_000)
+    if hasattr(gw, "close"):
+        torch.cuda.synchronize()
+        gw.close()
     torch.cuda.synchronize()
-    sg = parallel.SceneGather(total, (pool[0].C, pool[0].T), device=dev) if gather else None
+    sg = parallel.make_gather(args.gather, total, (pool[0].C, pool[0].T), device=dev) if gather else None
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -914,6 +923,11 @@ def run_scenes(args, rank, local_rank, world, dev):
             del plr
         verify = {"scenes_rerendered_by_rank0": checked, "mismatching": bad, "same_bits": not bad,
                   "shard_sizes": [len(x) for x in ranges]}
+    res_checksum = float(res.double().abs().mean().item()) if res is not None else None
+    if hasattr(sg, "close"):                   # the IPC gather's array goes back (collective: nobody closes it while a peer may still copy into it)
+        res = None
+        torch.cuda.synchronize()
+        sg.close()
     if rank != 0:
         return None
     audio_s = pool[0].T / pool[0].fs
@@ -1027,10 +1041,10 @@ def run_scenes(args, rank, local_rank, world, dev):
                             "the render; the NEXT scene's five K1 launches run on a second stream beside this scene's loudness / mix kernels), ONE ss_convolve_scene_f32 launch for the 3 moving + 2 static renders, ss_lufs_norm_batch_f32 (results stay on "
                             "the device; all gains are fetched once, inside the timed region), ss_mix_f32",
                    "T": spec.T, "P": len(pool[0].speakers[0][3]) + 1, "C": spec.C, "L": spec.L, "fs": spec.fs, "scenes_total": total,
-                   "dry_signal_pool": len(pool), "gather": gather, "distributed": args.dist_info,
+                   "dry_signal_pool": len(pool), "gather": (args.gather if gather else False), "distributed": args.dist_info,
                    "gathered_bytes_at_root": int(total * spec.C * spec.T * 4) if gather else 0,
                    "renders_per_second": total * 5 / dt, "rendered_audio_sec_per_sec": total * 5 * audio_s / dt},
-        "result_checksum": float(res.double().abs().mean().item()) if res is not None else None,
+        "result_checksum": res_checksum,
         "lufs_gain_mean": float(run.gains.mean()) if getattr(run, "gains", None) is not None else None,
         "roofline": roof,
         "cpu_baseline": cpu,
@@ -1459,6 +1473,9 @@ def main():
     ap.add_argument("--no-all-cores", action="store_true")
     ap.add_argument("--gather-every", type=int, default=5)
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--gather", default=os.environ.get("BENCH_GATHER", "rccl"), choices=["rccl", "ipc"],
+                    help="N > 1: how finished scenes reach rank 0 -- rccl = grouped send / recv (parallel.SceneGather, the default the north star names), "
+                         "ipc = the library's CU-free gather (ss_gather_*: HIP IPC handle + copy engines, parallel.IpcGather)")
     ap.add_argument("--serial", action="store_true", help="one stream: no overlap between consecutive independent renders (the profiler passes run this way)")
     ap.add_argument("--windows", type=int, default=7, help="timed K-step windows of the sustained section (value = the median window)")
     ap.add_argument("--event-windows", type=int, default=None)

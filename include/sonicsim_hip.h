@@ -353,6 +353,30 @@ int ss_prof_seen(int kind, int64_t* launches);
  * there are (bench.py reports min / median / p90 / max of the render kernel over the timed region) */
 int ss_prof_list(int kind, double* ms_out, int64_t cap, int64_t* launches);
 
+/* ---- multi-GPU gather WITHOUT compute units ("ss_gather_scenes"; round 6).  SonicSet.py:183-211 renders its scenes in
+ * one serial loop; here scenes shard over one process per GPU and only the finished (C, T) stems travel to the root.  The default path
+ * (sonicsim_amd/parallel.py SceneGather) moves them with RCCL send / recv, whose kernels take compute units from a render kernel built
+ * around owning all 256.  This path does not: the root exports its result array `scenes[num_scenes][scene_bytes]` as a HIP IPC handle,
+ * every other rank opens it and copies each finished scene straight into its slot with the copy engines (SDMA over xGMI / the local
+ * fabric: hipMemcpyAsync device-to-device on a copy stream of its own, ordered behind the render by an event).
+ *   root:   ss_gather_create(&g, num_scenes, scene_bytes, ipc_out)   -- allocates the array; the 64 bytes of ipc_out go to the other
+ *                                                                      ranks through the host framework's control plane (any transport)
+ *   others: ss_gather_attach(&g, ipc_in, num_scenes, scene_bytes)
+ *   all:    ss_gather_slot(g, i, &ptr)     root only: where scene i lives (render in place: nothing to copy)
+ *           ss_gather_put(g, i, src, stream)   enqueue "copy scene i from device memory `src` once `stream` has reached this point"; returns at
+ *                                              once; `src` may be rewritten after ss_gather_wait_src(g, stream) / ss_gather_flush
+ *           ss_gather_flush(g)             every put of this process has landed in the root's memory (host-side wait)
+ *           ss_gather_close(g)
+ * After all ranks flushed and met at a host barrier the root may read ss_gather_slot(g, i).  Device pointers only. */
+#define SS_IPC_HANDLE_BYTES 64
+int ss_gather_create(void** handle, int64_t num_scenes, int64_t scene_bytes, void* ipc_handle_out /* SS_IPC_HANDLE_BYTES */);
+int ss_gather_attach(void** handle, const void* ipc_handle_in, int64_t num_scenes, int64_t scene_bytes);
+int ss_gather_slot(void* handle, int64_t scene, void** ptr);
+int ss_gather_put(void* handle, int64_t scene, const void* src, void* stream);
+int ss_gather_wait_src(void* handle, void* stream);      /* `stream` waits for every put enqueued so far (their sources may then be rewritten by work on `stream`) */
+int ss_gather_flush(void* handle);
+int ss_gather_close(void* handle);
+
 #ifdef __cplusplus
 }
 #endif

@@ -114,6 +114,13 @@ _SIGS = {
                                                  ctypes.c_uint32, ctypes.c_void_p]),
     "ss_mix_presum_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int64, c_f32p, ctypes.c_float, ctypes.c_void_p,
                                          ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p]),
+    "ss_gather_create": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p]),
+    "ss_gather_attach": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64]),
+    "ss_gather_slot": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(ctypes.c_void_p)]),
+    "ss_gather_put": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]),
+    "ss_gather_wait_src": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
+    "ss_gather_flush": (ctypes.c_int, [ctypes.c_void_p]),
+    "ss_gather_close": (ctypes.c_int, [ctypes.c_void_p]),
     "ss_prof_enable": (ctypes.c_int, [ctypes.c_int]),
     "ss_prof_read": (ctypes.c_int, [ctypes.c_int, c_i64p, c_f64p]),
     "ss_prof_seen": (ctypes.c_int, [ctypes.c_int, c_i64p]),

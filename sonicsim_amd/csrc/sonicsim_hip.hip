@@ -4169,4 +4169,93 @@ int ss_prof_list(int kind, double* ms_out, int64_t cap, int64_t* launches) {
     return SS_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// CU-free scene gather (include/sonicsim_hip.h): IPC-shared result array on the root, copy-engine transfers from the other ranks
+struct SsGather {
+    bool root = false;
+    char* base = nullptr;          // root: hipMalloc'ed; others: hipIpcOpenMemHandle
+    int64_t num = 0, bytes = 0;
+    hipStream_t copy = nullptr;
+    hipEvent_t ev_in = nullptr, ev_out = nullptr;
+    int device = 0;
+};
+
+int ss_gather_create(void** handle, int64_t num_scenes, int64_t scene_bytes, void* ipc_handle_out) {
+    if (!handle || !ipc_handle_out || num_scenes < 1 || scene_bytes < 1) return fail(SS_EINVAL, "bad argument");
+    static_assert(sizeof(hipIpcMemHandle_t) <= SS_IPC_HANDLE_BYTES, "IPC handle size");
+    SsGather* g = new SsGather();
+    g->root = true; g->num = num_scenes; g->bytes = scene_bytes;
+    if (hipGetDevice(&g->device) != hipSuccess) { delete g; return fail(SS_ENODEV, "hipGetDevice failed"); }
+    hipError_t e = hipMalloc((void**)&g->base, (size_t)num_scenes * (size_t)scene_bytes);
+    if (e != hipSuccess) { delete g; return fail(SS_ENOMEM, "hipMalloc of the gather array (%lld bytes) failed: %s", (long long)(num_scenes * scene_bytes), hipGetErrorString(e)); }
+    hipIpcMemHandle_t h;
+    e = hipIpcGetMemHandle(&h, g->base);
+    if (e != hipSuccess) { hipFree(g->base); delete g; return fail(SS_EHIP, "hipIpcGetMemHandle failed: %s (HSA_ENABLE_IPC_MODE_LEGACY=0 needed on dmabuf-only hosts)", hipGetErrorString(e)); }
+    memset(ipc_handle_out, 0, SS_IPC_HANDLE_BYTES);
+    memcpy(ipc_handle_out, &h, sizeof(h));
+    if (hipStreamCreateWithFlags(&g->copy, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&g->ev_in, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&g->ev_out, hipEventDisableTiming) != hipSuccess) { hipFree(g->base); delete g; return fail(SS_EHIP, "stream / event creation failed"); }
+    *handle = g;
+    return SS_OK;
+}
+
+int ss_gather_attach(void** handle, const void* ipc_handle_in, int64_t num_scenes, int64_t scene_bytes) {
+    if (!handle || !ipc_handle_in || num_scenes < 1 || scene_bytes < 1) return fail(SS_EINVAL, "bad argument");
+    SsGather* g = new SsGather();
+    g->num = num_scenes; g->bytes = scene_bytes;
+    if (hipGetDevice(&g->device) != hipSuccess) { delete g; return fail(SS_ENODEV, "hipGetDevice failed"); }
+    hipIpcMemHandle_t h;
+    memcpy(&h, ipc_handle_in, sizeof(h));
+    hipError_t e = hipIpcOpenMemHandle((void**)&g->base, h, hipIpcMemLazyEnablePeerAccess);
+    if (e != hipSuccess) { delete g; return fail(SS_EHIP, "hipIpcOpenMemHandle failed: %s", hipGetErrorString(e)); }
+    if (hipStreamCreateWithFlags(&g->copy, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&g->ev_in, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&g->ev_out, hipEventDisableTiming) != hipSuccess) { hipIpcCloseMemHandle(g->base); delete g; return fail(SS_EHIP, "stream / event creation failed"); }
+    *handle = g;
+    return SS_OK;
+}
+
+int ss_gather_slot(void* handle, int64_t scene, void** ptr) {
+    SsGather* g = (SsGather*)handle;
+    if (!g || !ptr || scene < 0 || scene >= g->num) return fail(SS_EINVAL, "bad argument");
+    *ptr = g->base + scene * g->bytes;
+    return SS_OK;
+}
+
+int ss_gather_put(void* handle, int64_t scene, const void* src, void* stream_) {
+    SsGather* g = (SsGather*)handle;
+    if (!g || !src || scene < 0 || scene >= g->num) return fail(SS_EINVAL, "bad argument");
+    hipStream_t stream = (hipStream_t)stream_;
+    HIPCHK(hipEventRecord(g->ev_in, stream));                    // the copy starts once the producer (the render on `stream`) has finished
+    HIPCHK(hipStreamWaitEvent(g->copy, g->ev_in, 0));
+    HIPCHK(hipMemcpyAsync(g->base + scene * g->bytes, src, (size_t)g->bytes, hipMemcpyDeviceToDevice, g->copy));      // copy engines, no kernel
+    return SS_OK;
+}
+
+int ss_gather_wait_src(void* handle, void* stream_) {
+    SsGather* g = (SsGather*)handle;
+    if (!g) return fail(SS_EINVAL, "bad argument");
+    HIPCHK(hipEventRecord(g->ev_out, g->copy));
+    HIPCHK(hipStreamWaitEvent((hipStream_t)stream_, g->ev_out, 0));
+    return SS_OK;
+}
+
+int ss_gather_flush(void* handle) {
+    SsGather* g = (SsGather*)handle;
+    if (!g) return fail(SS_EINVAL, "bad argument");
+    HIPCHK(hipStreamSynchronize(g->copy));
+    return SS_OK;
+}
+
+int ss_gather_close(void* handle) {
+    SsGather* g = (SsGather*)handle;
+    if (!g) return SS_OK;
+    (void)hipStreamSynchronize(g->copy);
+    if (g->base) { if (g->root) (void)hipFree(g->base); else (void)hipIpcCloseMemHandle(g->base); }
+    if (g->copy) (void)hipStreamDestroy(g->copy);
+    if (g->ev_in) (void)hipEventDestroy(g->ev_in);
+    if (g->ev_out) (void)hipEventDestroy(g->ev_out);
+    delete g;
+    return SS_OK;
+}
+
 }  // extern "C"

@@ -163,6 +163,133 @@ class SceneGather:
         return self.result
 
 
+class IpcGather:
+    """SceneGather's interface on the library's CU-free gather (``ss_gather_*``, include/sonicsim_hip.h; round 6): rank 0 owns
+    ``result[num_scenes, ...]`` and exports it as a HIP IPC handle, every other rank opens it and copies each finished scene straight into
+    its slot with the copy engines (device-to-device ``hipMemcpyAsync`` on a copy stream of the library, ordered behind the render by an
+    event) -- no RCCL kernel runs beside the persistent render kernel, which is built around owning all 256 compute units.
+    ``torch.distributed`` is only the control plane here: the 64-byte handle is broadcast once, ``finish()`` ends with a barrier.
+
+    ``slot(j)`` / ``submit(j)`` / ``finish()`` as in SceneGather: rank 0 renders in place, the others into ``depth`` rotating buffers."""
+
+    def __init__(self, num_scenes: int, shape, dtype=None, device=None, dst: int = 0, depth: int = 2):
+        import ctypes
+
+        import numpy as np
+        import torch
+        import torch.distributed as dist
+
+        from . import _lib
+        self.torch, self.dist, self._lib, self.ctypes = torch, dist, _lib, ctypes
+        self.on = dist.is_initialized() and dist.get_world_size() > 1
+        self.rank = dist.get_rank() if self.on else 0
+        self.world = dist.get_world_size() if self.on else 1
+        self.dst, self.depth, self.num = dst, depth, num_scenes
+        self.ranges = [shard_range(num_scenes, r, self.world) for r in range(self.world)]
+        self.mine = self.ranges[self.rank]
+        dtype = dtype or torch.float32
+        self.shape = tuple(shape)
+        self.device = torch.device(device if device is not None else "cuda")
+        if self.device.type != "cuda":
+            raise ValueError("the IPC gather moves device memory: it needs a ROCm device")
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        n_el = int(np.prod(self.shape))
+        self.scene_bytes = n_el * torch.empty((), dtype=dtype).element_size()
+        lib = _lib.load()
+        self.h = ctypes.c_void_p()
+        blob = [None]
+        with torch.cuda.device(self.device):
+            if self.rank == dst:
+                ipc = (ctypes.c_ubyte * 64)()
+                _lib.check(lib.ss_gather_create(ctypes.byref(self.h), num_scenes, self.scene_bytes, ipc))
+                blob = [bytes(ipc)]
+            if self.on:
+                dist.broadcast_object_list(blob, src=dst)             # control plane: 64 bytes, once
+                if self.rank != dst:
+                    buf = (ctypes.c_ubyte * 64).from_buffer_copy(blob[0])
+                    _lib.check(lib.ss_gather_attach(ctypes.byref(self.h), buf, num_scenes, self.scene_bytes))
+        if self.rank == dst:
+            base = ctypes.c_void_p()
+            _lib.check(lib.ss_gather_slot(self.h, 0, ctypes.byref(base)))
+            self.result = _wrap_device_memory(torch, base.value, (num_scenes,) + self.shape, dtype, self.device, owner=self)
+            self.send = None
+        else:
+            self.result = None
+            self.send = [torch.empty(self.shape, dtype=dtype, device=self.device) for _ in range(depth)]
+        self._closed = False
+
+    def steps(self) -> int:
+        return max(len(r) for r in self.ranges)
+
+    def scene(self, j: int):
+        return self.mine[j] if j < len(self.mine) else None
+
+    def slot(self, j: int):
+        s = self.scene(j)
+        if s is None:
+            return None
+        if self.rank == self.dst:
+            return self.result[s]
+        if j >= self.depth:            # the copy that last read this buffer must be done before the render rewrites it (stream-ordered, no host wait)
+            self._lib.check(self._lib.load().ss_gather_wait_src(self.h, self.ctypes.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)))
+        return self.send[j % self.depth]
+
+    def submit(self, j: int):
+        s = self.scene(j)
+        if s is None or self.rank == self.dst:
+            return
+        src = self.send[j % self.depth]
+        self._lib.check(self._lib.load().ss_gather_put(self.h, int(s), self.ctypes.c_void_p(src.data_ptr()),
+                                                     self.ctypes.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)))
+
+    def finish(self):
+        """every rank's scenes have landed in rank 0's array on return (host-side: flush of this rank's copies, then a barrier)"""
+        self._lib.check(self._lib.load().ss_gather_flush(self.h))
+        if self.on:
+            self.dist.barrier()
+        return self.result
+
+    def close(self):
+        if not self._closed and self.h:
+            self._closed = True
+            if self.on:
+                self.dist.barrier()          # nobody closes the root's array while a peer may still copy into it
+            self.result = None
+            self._lib.load().ss_gather_close(self.h)
+
+    def __del__(self):
+        try:
+            if not self._closed and self.h and not self.on:
+                self._lib.load().ss_gather_close(self.h)
+        except Exception:               # noqa: BLE001 -- interpreter shutdown
+            pass
+
+
+def _wrap_device_memory(torch, ptr, shape, dtype, device, owner=None):
+    """a torch tensor over device memory this package allocated itself (the gather array must come from hipMalloc for the IPC export: torch's caching
+    allocator hands out sub-blocks).  Through ``__cuda_array_interface__``; the tensor keeps `owner` alive."""
+    import numpy as np
+    nbytes = int(np.prod(shape)) * torch.empty((), dtype=dtype).element_size()
+
+    class _Mem:
+        pass
+    m = _Mem()
+    m.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+    m.owner = owner
+    t = torch.as_tensor(m, device=device)
+    return t.view(dtype).view(shape)
+
+
+def make_gather(kind, num_scenes, shape, dtype=None, device=None, dst=0, depth=2):
+    """kind: 'rccl' (SceneGather: grouped send / recv, the north star's default) or 'ipc' (IpcGather: copy engines through a HIP IPC handle)"""
+    if kind in (None, "rccl", "nccl", "p2p"):
+        return SceneGather(num_scenes, shape, dtype=dtype, device=device, dst=dst, depth=depth)
+    if kind == "ipc":
+        return IpcGather(num_scenes, shape, dtype=dtype, device=device, dst=dst, depth=depth)
+    raise ValueError("gather kind must be 'rccl' or 'ipc'")
+
+
 def barrier_max_seconds(seconds: float, device=None) -> float:
     """MAX over ranks of a per-rank duration (bench.py timing contract)."""
     import torch

@@ -13,3 +13,7 @@ run () {  # name, args...
 }
 run cfg2 --steps 10 --warmup 2 --cpu-seconds 0
 run cfg4 --config cfg4 --steps 6 --warmup 1 --cpu-seconds 0
+# the same control flow through the library's CU-free gather (ss_gather_*: IPC handle + copy engines, parallel.IpcGather)
+export BENCH_GATHER=ipc HSA_ENABLE_IPC_MODE_LEGACY=0
+run cfg2_ipc --steps 10 --warmup 2 --cpu-seconds 0
+run cfg4_ipc --config cfg4 --steps 6 --warmup 1 --cpu-seconds 0
