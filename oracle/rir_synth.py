@@ -11,9 +11,11 @@ DEFINITION of the synthetic bank (SURVEY.md section 8d "Bank") that the HIP gene
     bank[p,c,t] = dgain[p,c] * [t == delay[p,c]]
                 + tail_gain * exp(-6.91 * t / (rt60*fs)) * n_p[c,t] * [t > delay[p,c]]
     n_0 = g_0 ;  n_p = rho * n_{p-1} + sqrt(1-rho^2) * g_p          (AR(1) across positions)
-    g_p[c,t] = sqrt(-2 ln u1) * (cos(2 pi u2) if n even else sin(2 pi u2)),   n = (p*C+c)*L+t  (global tap counter),
-               (u1, u2) = ((a >> 16) + 0.5, (a & 0xFFFF) + 0.5) * 2^-16,  a = hash32(seed, 1, n >> 1)   (both Box-Muller branches, one
-               hash per pair of taps)
+    g_p[c,t] = (b0 + b1 + b2 + b3 - 510) / sqrt(4 (256^2 - 1) / 12),   b_i = the four bytes of a (n even) / of remix(a) (n odd),
+               n = (p*C+c)*L+t  (global tap counter),  a = hash32(seed, 1, n >> 1),  remix(a) = h ^ (h >> 13), h = (a >> 7 & 0xFFFFFF) * 0xB5297A + a
+               (round 6: an Irwin-Hall sum of four uniform bytes -- zero mean, unit variance, kurtosis 2.7, |g| <= 3.45 -- instead of a
+               Box-Muller pair: no logarithm, square root, sine or cosine per tap pair on the device; one murmur finaliser per pair of taps
+               as before.  White to the resolution of 4 M samples: tests/test_oracle_rir_stats.py)
 
 Row G (``SonicSim_audio.py:111-127`` clip_all, ``:397`` stack/reshape, ``:398`` global peak
 normalise) is restated in ``clip_all`` / ``stack_and_normalise``.
@@ -50,16 +52,30 @@ def hash32(seed, stream, ctr):
     return h
 
 
+IH_SCALE = np.float32(1.0 / np.sqrt(4.0 * (256.0 ** 2 - 1.0) / 12.0))
+IH_OFFSET = np.float32(-510.0 * float(IH_SCALE))
+
+
+def remix(a):
+    """second word of a tap pair from its hash: a 24-bit multiply-add and one xor-shift (full-rate integer instructions on the device)"""
+    a = np.asarray(a, dtype=np.uint32)
+    h = ((((a >> np.uint32(7)).astype(np.uint64) & np.uint64(0xFFFFFF)) * np.uint64(0xB5297A) + a.astype(np.uint64)) & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+    return h ^ (h >> np.uint32(13))
+
+
+def byte_sum(h):
+    h = np.asarray(h, dtype=np.uint32)
+    return (h & np.uint32(0xFF)) + ((h >> np.uint32(8)) & np.uint32(0xFF)) + ((h >> np.uint32(16)) & np.uint32(0xFF)) + (h >> np.uint32(24))
+
+
 def gauss(seed, ctr):
-    """Standard normal of global tap counter `ctr`: Box-Muller with BOTH branches and ONE hash per pair -- the taps (2 i, 2 i + 1) share
-    a = hash32(seed, 1, i); u1 / u2 are its upper / lower 16 bits (round 3: one murmur finaliser, one log and one sqrt per two taps on the
-    device; the radius takes 65 536 levels, |g| <= 4.7)."""
+    """Unit-variance noise of global tap counter `ctr` (float32, exactly the device's value): the taps (2 i, 2 i + 1) share a = hash32(seed, 1, i);
+    tap 2 i sums the four bytes of a, tap 2 i + 1 those of remix(a); g = fma(float(sum), IH_SCALE, IH_OFFSET) in float32."""
     ctr = np.asarray(ctr, dtype=np.uint64)
     a = hash32(seed, 1, ctr >> np.uint64(1))
-    u1 = ((a >> np.uint32(16)).astype(np.float64) + 0.5) * 2.0 ** -16
-    u2 = ((a & np.uint32(0xFFFF)).astype(np.float64) + 0.5) * 2.0 ** -16
-    r = np.sqrt(-2.0 * np.log(u1))
-    return np.where((ctr & np.uint64(1)) == 0, r * np.cos(2.0 * np.pi * u2), r * np.sin(2.0 * np.pi * u2))
+    word = np.where((ctr & np.uint64(1)) == 0, a, remix(a))
+    s = byte_sum(word).astype(np.float64)
+    return (s * np.float64(IH_SCALE) + np.float64(IH_OFFSET)).astype(np.float32)      # one rounding: the product is exact in float64 (= fmaf)
 
 
 def rir_bank_synth(delay, dgain, L, fs, rt60, seed, tail_gain=0.05, rho=0.9):
@@ -76,7 +92,7 @@ def rir_bank_synth(delay, dgain, L, fs, rt60, seed, tail_gain=0.05, rho=0.9):
     for p in range(P):
         ctr = (np.uint64(p) * np.uint64(C) + np.arange(C, dtype=np.uint64)[:, None]) * np.uint64(L) \
             + np.arange(L, dtype=np.uint64)[None, :]
-        g = gauss(seed, ctr).astype(np.float32)
+        g = gauss(seed, ctr)
         if n_prev is None:
             n = g
         else:

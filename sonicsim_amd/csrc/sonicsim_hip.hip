@@ -628,18 +628,19 @@ __device__ __forceinline__ uint32_t hash32(uint32_t seed, uint32_t stream, uint6
     uint32_t h = fmix32((uint32_t)(ctr >> 32) ^ k);
     return fmix32((uint32_t)ctr ^ h);
 }
-__device__ __forceinline__ float unit16(uint32_t h16) { return __builtin_fmaf((float)h16, 1.52587890625e-5f, 7.62939453125e-6f); }   // (k + 0.5) 2^-16
-// Box-Muller with the hardware transcendentals (v_log_f32 = log2, v_cos_f32 / v_sin_f32 take revolutions), BOTH branches, ONE hash per
-// pair of taps (round 3): the taps with global counters (2 i, 2 i + 1) share a = hash32(seed, 1, i); u1 / u2 are its upper / lower 16 bits:
-//     g[2 i] = sqrt(-2 ln u1) cos(2 pi u2),   g[2 i + 1] = sqrt(-2 ln u1) sin(2 pi u2),   u = (16 bits + 0.5) 2^-16
-// (independent standard normals, radius quantised to 65 536 levels, |g| <= 4.7) -- one murmur finaliser, one log2, one sqrt per TWO taps
-// instead of two finalisers, a log2 and a sqrt per tap (oracle/rir_synth.py::gauss is the definition; tools/ubench/k1_variants.hip: 89 ->
-// 73 us per 307 MB bank, 62 with the positions unrolled by two).
-__device__ __forceinline__ void box_muller2(uint32_t a, float& g0, float& g1) {
-    const float r = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(unit16(a >> 16)));
-    const float u2 = unit16(a & 0xFFFFu);
-    g0 = r * __builtin_amdgcn_cosf(u2);
-    g1 = r * __builtin_amdgcn_sinf(u2);
+// Unit-variance noise for a PAIR of taps from ONE hash (round 6; oracle/rir_synth.py::gauss is the definition): an Irwin-Hall sum of four uniform
+// bytes per tap -- zero mean, unit variance, kurtosis 2.7, |g| <= 3.45 -- the bytes of a for the even tap, of remix(a) for the odd one.
+//     g = fma(float(b0 + b1 + b2 + b3), 1 / sqrt(4 (256^2 - 1) / 12), -510 / sqrt(...))          remix(a) = h ^ (h >> 13),  h = (a >> 7)[23:0] * 0xB5297A + a
+// Seven full-rate integer / float instructions per pair (v_sad_u8 sums the bytes) where rounds 3-5 ran a Box-Muller pair: a log2, a square root, a
+// sine and a cosine -- four quarter-rate transcendentals -- per pair.  The generator is this repository's own definition (row R's parity is
+// unpinned: the reference's RIRs come from closed-source RLR); whiteness and moments: tests/test_oracle_rir_stats.py.
+__device__ __forceinline__ void noise_pair(uint32_t a, float& g0, float& g1) {
+    constexpr float SC = 0.006765875034034252f;           // 1 / sqrt(21845)
+    constexpr float OF = -3.450596332550049f;             // -510 * SC  (both rounded to float32 exactly as oracle/rir_synth.py: IH_SCALE, IH_OFFSET)
+    uint32_t h = __umul24(a >> 7, 0xB5297Au) + a;
+    h ^= h >> 13;
+    g0 = __builtin_fmaf((float)__builtin_amdgcn_sad_u8(a, 0u, 0u), SC, OF);
+    g1 = __builtin_fmaf((float)__builtin_amdgcn_sad_u8(h, 0u, 0u), SC, OF);
 }
 
 // FAST32: the bank has fewer than 2^33 samples, so the high word of every PAIR counter is 0 and the first mixing round of hash32 is one
@@ -675,13 +676,13 @@ __device__ __forceinline__ void rir_synth_body(const RirDev& p, float* __restric
         if (V == 1) {
             const uint64_t pr = ctr >> 1;
             float g0, g1;
-            box_muller2(FAST32 ? fmix32((uint32_t)pr ^ h1c) : fmix32((uint32_t)pr ^ fmix32((uint32_t)(pr >> 32) ^ k1)), g0, g1);
+            noise_pair(FAST32 ? fmix32((uint32_t)pr ^ h1c) : fmix32((uint32_t)pr ^ fmix32((uint32_t)(pr >> 32) ^ k1)), g0, g1);
             g[0] = (ctr & 1) ? g1 : g0;
         } else {
 #pragma unroll
             for (int v = 0; v < V; v += 2) {
                 const uint64_t pr = (ctr + (uint64_t)v) >> 1;
-                box_muller2(FAST32 ? fmix32((uint32_t)pr ^ h1c) : fmix32((uint32_t)pr ^ fmix32((uint32_t)(pr >> 32) ^ k1)), g[v], g[v + (V > 1 ? 1 : 0)]);
+                noise_pair(FAST32 ? fmix32((uint32_t)pr ^ h1c) : fmix32((uint32_t)pr ^ fmix32((uint32_t)(pr >> 32) ^ k1)), g[v], g[v + (V > 1 ? 1 : 0)]);
             }
         }
         float val[V];

@@ -32,6 +32,49 @@ def test_compat_modules_pass_reference_names_through(tmp_path):
     assert r.returncode == 0 and "ok" in r.stdout, r.stderr
 
 
+def test_accelerated_names_never_resolve_to_the_references_objects(tmp_path):
+    """sonicsim_amd/compat/_passthrough.py executes the reference's same-named module -- the one place where product code loads
+    reference code.  It must stay exactly that narrow: a reference module that DEFINES every accelerated name (as the real one does) loses each of
+    them to this package, and only the names the package does not serve come through."""
+    ref = tmp_path / "SonicSim-SonicSet"
+    ref.mkdir()
+    code = textwrap.dedent(f"""
+        import importlib, sys
+        sys.path.insert(0, {ROOT!r})
+        names = {{}}
+        for m in ('SonicSim_moving', 'SonicSim_audio', 'SonicSim_rir'):
+            impl = importlib.import_module('sonicsim_amd.' + m)
+            names[m] = sorted(n for n in dir(impl) if not n.startswith('_') and callable(getattr(impl, n)) and getattr(getattr(impl, n), '__module__', '').startswith('sonicsim_amd'))
+        import json; print(json.dumps(names))
+    """)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    import json
+    served = json.loads(r.stdout.strip().splitlines()[-1])
+    nine = ["setup_dynamic_interp", "convolve_fixed_receiver", "convolve_moving_receiver", "interpolate_moving_audio"]
+    assert all(n in served["SonicSim_moving"] for n in nine)
+    for m, ns in served.items():
+        body = "".join(f"def {n}(*a, **k):\n    return 'REFERENCE {n}'\n" for n in ns)
+        body += "def only_the_reference_has_this():\n    return 'reference'\nclass Scene:\n    pass\n"
+        (ref / (m + ".py")).write_text(body)
+    code = textwrap.dedent(f"""
+        import sys, json
+        sys.path[:0] = [{str(os.path.join(ROOT, 'sonicsim_amd', 'compat'))!r}, {str(ref)!r}]
+        import SonicSim_moving, SonicSim_audio, SonicSim_rir
+        served = json.loads({json.dumps(served)!r})
+        for mod in (SonicSim_moving, SonicSim_audio, SonicSim_rir):
+            assert mod.REFERENCE_SOURCE and mod.REFERENCE_SOURCE.endswith(mod.__name__ + '.py'), mod.REFERENCE_SOURCE      # the fake reference WAS executed
+            assert mod.only_the_reference_has_this() == 'reference' and mod.Scene.__module__.startswith('_sonicsim_reference_')
+            for n in served[mod.__name__]:
+                f = getattr(mod, n)
+                assert f.__module__.startswith('sonicsim_amd'), (mod.__name__, n, f.__module__)
+                assert n in mod.ACCELERATED
+        print('ok', sum(len(v) for v in served.values()))
+    """)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "ok" in r.stdout, (r.stdout, r.stderr)
+
+
 def test_a_bug_in_the_users_reference_module_is_not_swallowed(tmp_path):
     """only ImportError (a missing third-party package) degrades to "accelerated names only"; a genuine error in a user's modified
     reference file propagates (round-3 verdict: `except Exception` hid it)"""
