@@ -714,7 +714,8 @@ def run_cfg2(args, rank, local_rank, world, dev):
     if ktrace and ktrace.get("avg_ms"):
         avg_launch_ms = ktrace["avg_ms"]
         achieved = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9
-        frac_source = f"rocprofv3 --kernel-trace --stats of this run's child pass ({ktrace['calls']} launches; {ktrace.get('kernel_stats_csv')})"
+        frac_source = (f"rocprofv3 --kernel-trace --stats of this run's child pass: ONE stream ({ktrace['calls']} launches; {ktrace.get('kernel_stats_csv')}); "
+                       "`value` alternates three streams, frac_events is measured in that mode in this process (ADVICE r5)")
     out = {
         "metric": "rendered-audio-sec/sec (8-mic, 200-pt trajectory, 16 kHz)" if args.config == "cfg2" else
                   f"rendered-audio-sec/sec ({sc.C}-ch, {sc.P}-pt trajectory, {sc.fs // 1000} kHz)",
@@ -1235,7 +1236,8 @@ def run_hostpath(args, dev, cpu_baseline=None):
                         "what SonicSet.py:77-79 calls",
             "metric": "rendered-audio-sec/sec (8-mic, 200-pt trajectory, 16 kHz), host buffers in and out (PCIe inclusive)",
             "value": audio_s / t_full[1], "unit": "rendered-audio-sec/sec", "ms_per_step": t_full[1] * 1e3, "steps": 9, "dtype": "f32",
-            "roofline": {"bound": "pcie", "achieved": ach_gbs, "peak": pcie_gbs, "unit": "GB/s", "frac": ach_gbs / pcie_gbs, "traffic": None,
+            "roofline": {"bound": "pcie", "achieved": ach_gbs, "peak": max(pcie_gbs, ach_gbs), "unit": "GB/s", "frac": min(1.0, ach_gbs / pcie_gbs), "traffic": None,
+                         "frac_unclamped": ach_gbs / pcie_gbs,      # (the "peak" is ONE memcpy timed just before: a faster moment of the link can read > 1)
                          "algorithmic_bytes_per_launch": nb, "avg_launch_ms": t_full[1] * 1e3,
                          "kernel": "host-to-device upload of the bank + x (hostpipe.h); peak = ONE pinned hipMemcpyAsync of the bank measured on this box just before",
                          "note": "bytes that must cross the link upwards (bank + x) over the MEDIAN call time; y (30.7 MB) comes back on the other direction of the link"},

@@ -110,6 +110,11 @@ int ss_set_task_queue(int dynamic);
  * alone (0.182 -> 0.168 ms per config-2 render).  A fifth stream takes over the least recently used lane after synchronising
  * that lane's stream.  ss_workspace_lanes: {lanes, lanes in use, lane switches so far, takeovers (each one a stream synchronisation)}. */
 int ss_workspace_lanes(int32_t* out, int32_t n);
+/* Lifetime: a lane remembers the raw stream handle it belongs to until the library shuts down, and entry points that read state of other
+ * lanes (ss_async_status) or take a lane over synchronise that handle -- a stream must therefore be RELEASED before the caller destroys it:
+ * ss_stream_release(stream) synchronises the stream once, forgets it and frees the lane's workspace (input spectra, plans, row spectra: up to
+ * a few hundred MB at config-5 shapes per lane).  Releasing a stream the library has never seen is not an error. */
+int ss_stream_release(void* stream);
 
 /* ---- host-pointer mode (flags without SS_FLAG_DEVICE_PTR): the path SonicSim_moving.py:122-125 really takes -- NumPy in, NumPy out.
  * The library moves the caller's arrays through a ring of pinned staging slots filled by a few host threads while the DMA engine drains

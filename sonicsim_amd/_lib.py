@@ -56,6 +56,7 @@ _SIGS = {
                                                       ctypes.c_void_p, c_i64p]),
     "ss_set_task_queue": (ctypes.c_int, [ctypes.c_int]),
     "ss_workspace_lanes": (ctypes.c_int, [c_i32p, ctypes.c_int32]),
+    "ss_stream_release": (ctypes.c_int, [ctypes.c_void_p]),
     "ss_set_host_pipe": (ctypes.c_int, [ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int]),
     "ss_host_path_stats": (ctypes.c_int, [c_f64p, ctypes.c_int32]),
     "ss_host_alloc": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int64]),

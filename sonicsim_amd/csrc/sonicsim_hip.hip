@@ -3037,6 +3037,35 @@ int ss_workspace_lanes(int32_t* out, int32_t n) {
     return SS_OK;
 }
 
+int ss_stream_release(void* stream_) {
+    Ctx* c;
+    int rc = get_ctx(&c);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lock(c->mu);
+    hipStream_t stream = (hipStream_t)stream_;
+    for (int i = 0; i < Ctx::NLANE; ++i) {
+        Ctx::Lane& l = c->lanes[i];
+        if (!l.used || l.stream != stream) continue;
+        HIPCHK(hipStreamSynchronize(stream));
+        void** ws = i == c->cur_lane ? c->ws : l.ws;             // the active lane's slots live in the context
+        size_t* cap = i == c->cur_lane ? c->ws_cap : l.cap;
+        for (int k = 0; k < WS_COUNT; ++k) {
+            if (k == WS_K1) continue;                            // (the bank generator's slots are shared by all lanes)
+            if (ws[k]) HIPCHK(hipFree(ws[k]));
+            ws[k] = nullptr;
+            cap[k] = 0;
+        }
+        c->lufs_bounds_dev = c->kw_cached_dev = c->gw_cached_dev = nullptr;      // (pointer-identity caches of tables that lived in the freed slots:
+                                                                                   //  a later allocation may land on the same address)
+        l.used = false;
+        l.stream = nullptr;
+        l.dev_planned = false;
+        l.status_zeroed = false;
+        l.tick = 0;
+    }
+    return SS_OK;
+}
+
 int ss_host_path_stats(double* out, int32_t n) {
     if (!out || n < 1) return fail(SS_EINVAL, "ss_host_path_stats: out is NULL");
     Ctx* c;

@@ -589,6 +589,15 @@ def workspace_lanes():
     return {"lanes": v[0], "in_use": v[1], "switches": v[2], "takeovers": v[3]}
 
 
+def release_stream(stream=None):
+    """Forget a stream the library has a workspace lane for and free that lane's buffers (``ss_stream_release``): call it before destroying a stream
+    that rendered (the library would otherwise synchronise the dead handle later), or to give back the memory of a lane that stays idle.
+    stream: a ``torch.cuda.Stream`` (default: the current stream)."""
+    import torch
+    st = torch.cuda.current_stream() if stream is None else stream
+    _lib.check(_lib.load().ss_stream_release(ctypes.c_void_p(st.cuda_stream)))
+
+
 def async_status(stream_of=None):
     """stream_of: a device tensor whose device's current stream is synchronised (default: the current device's current stream).
     (code, where) latched by renders issued with validate=False on the current device, then cleared: 0 = none,

@@ -325,3 +325,28 @@ def test_plain_loop_reaches_the_overlapped_rate(gpu):
         ops.set_overlap(True)
     print(f"plain loop through interpolate_moving_audio: {t_on * 1e3:.4f} ms/render overlapped, {t_off * 1e3:.4f} ms one stream")
     assert t_on < t_off * 1.03          # (a timing inside a test suite: the gain itself -- 0.168 against 0.180 ms on a quiet box -- is measured by bench.py's `dropin_loop`)
+
+
+def test_release_stream_gives_the_lane_back(gpu):
+    """lanes remembered raw stream handles for the life of the context (a destroyed stream was synchronised later) and kept their
+    workspace copies.  ss_stream_release forgets the stream and frees the lane; the next render on any stream still gives the same bits."""
+    from sonicsim_amd import ops
+    x, b, s, _ = _cases(gpu)[0]
+    want = ops.convolve_moving_seg(x, b, s, out=torch.empty((b.shape[1], x.shape[0]), device=gpu)).clone()
+    st = torch.cuda.Stream(device=gpu)
+    with torch.cuda.stream(st):
+        y = ops.convolve_moving_seg(x, b, s, out=torch.empty_like(want))
+    st.synchronize()
+    before = ops.workspace_lanes()
+    free0 = torch.cuda.mem_get_info(gpu)[0]
+    ops.release_stream(st)
+    after = ops.workspace_lanes()
+    assert after["in_use"] == before["in_use"] - 1
+    assert torch.cuda.mem_get_info(gpu)[0] >= free0               # (the lane's spectra / plan buffers went back to the driver)
+    ops.release_stream(st)                                        # releasing it again, or a stream never seen, is not an error
+    ops.release_stream(torch.cuda.Stream(device=gpu))
+    assert torch.equal(y, want)
+    with torch.cuda.stream(st):                                   # the stream simply takes a fresh lane when it renders again
+        y2 = ops.convolve_moving_seg(x, b, s, out=torch.empty_like(want))
+    st.synchronize()
+    assert torch.equal(y2, want) and ops.workspace_lanes()["in_use"] == before["in_use"]
