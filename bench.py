@@ -237,6 +237,8 @@ def _roof_compact(r):
         return None
     out = _pick(r, ("bound", "achieved", "peak", "unit", "frac", "frac_events", "frac_source", "traffic", "algorithmic_bytes_per_launch",
                     "avg_launch_ms", "avg_launch_ms_events", "launches_per_render"))
+    if isinstance(out.get("frac_source"), str) and len(out["frac_source"]) > 96:
+        out["frac_source"] = out["frac_source"][:93] + "..."
     if "kernel" in r:
         out["kernel"] = str(r["kernel"]).split(" ")[0].rstrip(",")
     if isinstance(r.get("compute"), dict):

@@ -46,7 +46,7 @@ extern "C" {
 #define SS_FLAG_RESULT_DEVICE 0x2000u /* ss_lufs_norm_batch_f32 with SS_FLAG_DEVICE_PTR: `result` is a DEVICE array of 4 * S doubles; the call only enqueues work (no synchronisation) */
 #define SS_FLAG_KEEP_SPEAKERS 0x4000u /* ss_mix_f32: do not write the scaled interferers back into `speakers` (read-only input; the mix is the only output) */
 #define SS_FLAG_BANK_DEVICE 0x8000u /* render entry points WITHOUT SS_FLAG_DEVICE_PTR: `rirs` alone is a DEVICE pointer (a resident bank rendered for a host dry signal into a host array) */
-#define SS_FLAG_ROW_SPECTRA 0x10000u /* render entry points, assembly engine: transform EVERY filter row once in a pre-pass (default: only rows cut into >= 3 tasks, i.e. trajectories of few points, and static sources; csrc/plan.h flag_long_rows) */
+#define SS_FLAG_ROW_SPECTRA 0x10000u /* render entry points, assembly engine: transform EVERY filter row once in a pre-pass (default: only rows cut into >= 5 tasks, i.e. trajectories of few points, and static sources; csrc/plan.h flag_long_rows) */
 #define SS_FLAG_NO_ROW_SPECTRA 0x20000u /* ... never: every task transforms its row's taps itself (the only form before round 6) */
 #define SS_FLAG_ASYNC_PLAN 0x800u /* ss_convolve_moving_f32 with device pointers: plan the explicit schedule on the device (no host synchronisation) */
 

@@ -2089,14 +2089,17 @@ int load_mod13(Ctx* c, bool dynq = false) {
 }
 
 // Rows cut into many tasks are transformed once (plan.h flag_long_rows): marks the tasks of `tasks`, sizes the spectra array and fills
-// `ha` for the pre-pass.  Policy: automatic = rows of >= 3 tasks while the array stays within 128 MB (it is read once per task: it has to
-// stay in the L2s / the Infinity Cache to pay -- larger sets, e.g. config 5's two-task rows, keep the transforming tasks; LAB round 6);
+// `ha` for the pre-pass.  Policy: automatic = rows of >= 5 tasks while the array stays within 96 MB.  Measured (profiles/r06w, trajectories of
+// 2 .. 200 points at config-2 shapes): a pre-pass transform costs ~1.2 x a transforming interval of the render kernel and a spectra-ready
+// interval saves ~2/3 of one, so rows of 3-4 tasks (P = 40 .. 64 there, config 5's longest rows) LOSE -- 0.132 -> 0.151 ms at P = 40 with the
+// round's first threshold of 3 -- rows of 5-6 tasks are even, rows of >= 11 (P <= 12, static sources) gain 15-20 %; the array is read once
+// per task and has to stay in the L2s / the Infinity Cache to pay (LAB round 6);
 // SS_FLAG_ROW_SPECTRA marks every row (tests, measurements), SS_FLAG_NO_ROW_SPECTRA none.
 int hrow_mark(Ctx* c, std::vector<Task>& tasks, const int32_t* Ps, int nsrc, int C, int NPart, uint32_t flags, HRowArgs& ha) {
     ha.nrows = 0;
     if (flags & SS_FLAG_NO_ROW_SPECTRA) return SS_OK;
-    static const int hrow_min = knob("SS_HROW_MIN") ? atoi(knob("SS_HROW_MIN")) : 3;
-    static const int64_t hrow_mb = knob("SS_HROW_MB") ? atoll(knob("SS_HROW_MB")) : 128;
+    static const int hrow_min = knob("SS_HROW_MIN") ? atoi(knob("SS_HROW_MIN")) : 5;
+    static const int64_t hrow_mb = knob("SS_HROW_MB") ? atoll(knob("SS_HROW_MB")) : 96;
     const bool force = (flags & SS_FLAG_ROW_SPECTRA) != 0;
     for (int s = 0; s < nsrc; ++s) if (Ps[s] > 0xffffff) return SS_OK;
     static thread_local std::vector<int32_t> rows;

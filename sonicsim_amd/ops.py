@@ -20,7 +20,7 @@ _PendingTensor = None          # torch.Tensor subclass of lazily joined render o
 PATHS = {None: 0, "auto": 0, "os": _lib.FLAG_PATH_OS, "direct": _lib.FLAG_PATH_DIRECT,
          "os2048": _lib.FLAG_PATH_OS | _lib.FLAG_GEOM_2048, "os4096": _lib.FLAG_PATH_OS | _lib.FLAG_GEOM_4096,
          "os13": _lib.FLAG_PATH_OS | _lib.FLAG_GEOM_13, "asm": _lib.FLAG_PATH_OS | _lib.FLAG_GEOM_ASM,
-         # the assembly engine with EVERY filter row transformed once by the pre-pass / with none (default: rows cut into >= 3 tasks)
+         # the assembly engine with EVERY filter row transformed once by the pre-pass / with none (default: rows cut into >= 5 tasks)
          "asm+rows": _lib.FLAG_PATH_OS | _lib.FLAG_GEOM_ASM | _lib.FLAG_ROW_SPECTRA,
          "asm-rows": _lib.FLAG_PATH_OS | _lib.FLAG_GEOM_ASM | _lib.FLAG_NO_ROW_SPECTRA}
 
@@ -707,7 +707,7 @@ def convolve_scene(xs, banks, segs, peaks=None, outs=None, row_spectra=None):
     and two static sources one after the other).  xs: n dry signals (T,); banks[i]: (P, C, L) for a moving source (segs[i] = its P - 1
     segment lengths, sum T) or (C, L) / (1, C, L) for a static one (segs[i] None); peaks[i]: optional one-element device tensor (deferred
     peak normalisation of that bank); outs: optional n (C, T) float32 device tensors (e.g. rows of a stem stack).  Device tensors only.
-    row_spectra: None = automatic (static sources and rows cut into >= 3 tasks are transformed once by the pre-pass), True = every row,
+    row_spectra: None = automatic (static sources and rows cut into >= 5 tasks are transformed once by the pre-pass), True = every row,
     False = none.  Returns the list of outputs -- bit-identical to convolve_moving_seg / convolve_fixed called one by one with the same choice."""
     import torch
     lib = _lib.load()
