@@ -293,7 +293,7 @@ def compact_line(full, limit=LINE_LIMIT):
     """The final stdout line: the contract's keys + roofline + cpu_baseline + a flat `secondary` summary, at most `limit` bytes.  `full` is what
     the run_* functions return (everything measured); it goes to the `[detail]` / `[leg]` lines printed before and to gpurun_out/bench_detail.json."""
     head = _pick(full, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
-                        "data", "value_cold", "ms_per_step_cold", "ms_per_step_latency", "parity_rel_rms_vs_oracle", "speedup_vs_cpu_baseline",
+                        "data", "value_cold", "ms_per_step_cold", "ms_per_step_latency", "ms_per_step_dropin_loop", "parity_rel_rms_vs_oracle", "speedup_vs_cpu_baseline",
                         "result_checksum"))
     cfg = full.get("config") or {}
     c = _pick(cfg, ("workload", "T", "P", "C", "L", "fs", "entry_point", "parallelism", "scenes_total", "gathered_bytes_at_root", "gather", "streams"))
@@ -657,6 +657,42 @@ def run_cfg2(args, rank, local_rank, world, dev):
         for _ in range(3):
             rec, _yy = window(False, serial=True)
             serial_windows.append(rec["dt"] / args.steps * 1e3)
+    # ---- the plain loop a user of the drop-in writes: SonicSim_moving.interpolate_moving_audio on ROCm tensors, no block, no out= --
+    #      round 6's implicit overlap puts the renders on alternating side streams by itself; the same loop with the overlap switched off beside it
+    dropin = None
+    if world == 1 and args.config == "cfg2" and not os.environ.get("BENCH_IN_PMC"):
+        try:
+            from sonicsim_amd import SonicSim_moving as M
+            xs1, irs, posl = x[None], bank[:, None], list(sc.positions)
+
+            def loop(k):
+                keep = []
+                np.random.seed(4000)                          # (the segment lengths' RNG-coupled host half runs in every call, like in SonicSet.py)
+                for _ in range(k):
+                    keep.append(M.interpolate_moving_audio(xs1, irs, posl))
+                    if len(keep) > 3:
+                        keep.pop(0)
+                torch.cuda.synchronize()
+
+            def rate():
+                loop(args.warmup + 5)
+                ts = []
+                for _ in range(3):
+                    t0 = time.perf_counter()
+                    loop(args.steps)
+                    ts.append((time.perf_counter() - t0) / args.steps)
+                return sorted(ts)[1] * 1e3
+            on = rate()
+            ops.set_overlap(False)
+            try:
+                off = rate()
+            finally:
+                ops.set_overlap(True)
+            dropin = {"ms_per_step": on, "ms_per_step_overlap_off": off,
+                      "what": "plain Python loop of SonicSim_moving.interpolate_moving_audio(ROCm tensors), fresh output per call; implicit overlap "
+                              "(ops.set_overlap, default on) vs switched off; median of 3 windows of K steps"}
+        except Exception as e:                                # noqa: BLE001 -- informational
+            dropin = {"error": repr(e)[:200]}
     if not ev_windows:
         ev_windows = [dict(windows[0])]
     if not windows:
@@ -735,6 +771,8 @@ def run_cfg2(args, rank, local_rank, world, dev):
         "value_cold": world * args.steps * audio_s / dt_cold,
         "ms_per_step_cold": dt_cold / args.steps * 1e3,
         "ms_per_step_latency": sorted(serial_windows)[len(serial_windows) // 2] if serial_windows else dt / args.steps * 1e3,
+        "ms_per_step_dropin_loop": (dropin or {}).get("ms_per_step"),
+        "dropin_loop": dropin,
         "streams": {"render_streams": nstreams if overlap else 1,
                     "how": (f"independent renders alternate over {nstreams} streams (ops.RenderStreams; one workspace lane per stream in the library): the following "
                             "renders' spectra launches fill the compute units a persistent launch frees at its end and the next persistent launch starts on them; "
