@@ -1319,13 +1319,15 @@ constexpr int KW_SER = 8;        // chunks each scan thread walks serially
 constexpr int KW_TILE = 512;     // threads of the scan workgroup: one tile = KW_TILE * KW_SER chunks
 static_assert(KW_SER == 8 && KW_TILE == 512, "the scan's power indices (Mp[3+b], Mp[9+b], Mp[12]) assume 8 chunks/thread, 8 waves");
 
+// (round 6: written as explicit FMA chains -- 5 float64 operations per biquad step where the compiler's own contraction of the textbook form
+//  left 7-8; the recurrence is the kernel's instruction-issue bound.  Rounding differs from SciPy's unfused lfilter in the last bit, like before.)
 __device__ __forceinline__ double kw_step(const KwCoef& k, double s[4], double xin) {
-    const double y1 = k.b[0][0] * xin + s[0];
-    s[0] = k.b[0][1] * xin - k.a[0][1] * y1 + s[1];
-    s[1] = k.b[0][2] * xin - k.a[0][2] * y1;
-    const double y2 = k.b[1][0] * y1 + s[2];
-    s[2] = k.b[1][1] * y1 - k.a[1][1] * y2 + s[3];
-    s[3] = k.b[1][2] * y1 - k.a[1][2] * y2;
+    const double y1 = fma(k.b[0][0], xin, s[0]);
+    s[0] = fma(k.b[0][1], xin, fma(-k.a[0][1], y1, s[1]));
+    s[1] = fma(k.b[0][2], xin, -k.a[0][2] * y1);
+    const double y2 = fma(k.b[1][0], y1, s[2]);
+    s[2] = fma(k.b[1][1], y1, fma(-k.a[1][1], y2, s[3]));
+    s[3] = fma(k.b[1][2], y1, -k.a[1][2] * y2);
     return y2;
 }
 __device__ __forceinline__ void kw_matvec(const double* M, const double s[4], double o[4]) {
@@ -1361,7 +1363,7 @@ __device__ __forceinline__ void kw_endstate(const float* __restrict__ a, int64_t
             const double x0 = (double)q[i].x, x1 = (double)q[i].y, x2 = (double)q[i].z, x3 = (double)q[i].w;
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                v[r] += k.W[4 * i][r] * x0 + k.W[4 * i + 1][r] * x1 + k.W[4 * i + 2][r] * x2 + k.W[4 * i + 3][r] * x3;
+                v[r] = fma(k.W[4 * i + 3][r], x3, fma(k.W[4 * i + 2][r], x2, fma(k.W[4 * i + 1][r], x1, fma(k.W[4 * i][r], x0, v[r]))));
         }
     } else {
         const int off = KW_CHUNK - (int)(t1 - t0);
