@@ -18,6 +18,7 @@ from oracle import moving as O  # noqa: E402  (checker only)
 from sonicsim_amd import ops, synth  # noqa: E402
 
 label = sys.argv[1] if len(sys.argv) > 1 else "variant"
+ops.set_overlap(False)          # event-timed kernels: one stream
 dev = torch.device("cuda:0")
 ops.init(0)
 res = []

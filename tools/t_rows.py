@@ -38,6 +38,7 @@ def bank_for(P, C, L, seed):
 
 def ktime(fn, n=20, warm=3):
     """(wall ms per call, render-kernel us, pre-pass us, spectra us) by HIP events around the launches"""
+    ops.set_overlap(False)          # (event-timed kernels need one stream: with the implicit overlap of round 6 consecutive launches share the machine)
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
