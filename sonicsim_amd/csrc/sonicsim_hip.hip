@@ -342,8 +342,8 @@ __device__ __forceinline__ void plan_explicit_body(PlanDevArgs a) {
             for (int k = 0; k < PF; ++k) {
                 const long long u = (long long)k * nt + tid;
                 const bool ok = u < units && u < a.nfine;
-                pl[k] = ok ? a.bmin[u] : 0;
-                ph[k] = ok ? a.bmax[u] : 0;
+                pl[k] = ok ? ld_agent(a.bmin + u) : 0;
+                ph[k] = ok ? ld_agent(a.bmax + u) : 0;
             }
         }
         int round = 0;
@@ -356,7 +356,7 @@ __device__ __forceinline__ void plan_explicit_body(PlanDevArgs a) {
                     l = pl[0]; h = ph[0];
 #pragma unroll
                     for (int k = 1; k < PF; ++k) if (round == k) { l = pl[k]; h = ph[k]; }
-                } else { l = a.bmin[u]; h = a.bmax[u]; }
+                } else { l = ld_agent(a.bmin + u); h = ld_agent(a.bmax + u); }
                 if (l < 0 || h > a.P - 2) {
                     if (atomicCAS(&a.status[0], 0, 1) == 0) a.status[1] = (int32_t)(u < INT32_MAX ? u : INT32_MAX);
                     atomicMin(&oor_tile, (int)(u < INT32_MAX ? u : INT32_MAX - 1));
@@ -382,7 +382,7 @@ __device__ __forceinline__ void plan_explicit_body(PlanDevArgs a) {
         for (int f = 0; f < a.fine_per_block; ++f) {
             const int64_t fb = (int64_t)j * a.fine_per_block + f;
             if (fb < a.nfine) {
-                const int l = a.bmin[fb], h = a.bmax[fb];
+                const int l = ld_agent(a.bmin + fb), h = ld_agent(a.bmax + fb);
                 if (l < 0 || h > a.P - 2) {
                     if (atomicCAS(&a.status[0], 0, 1) == 0) a.status[1] = (int32_t)(fb < INT32_MAX ? fb : INT32_MAX);
                     atomicMin(&oor_tile, (int)(fb < INT32_MAX ? fb : INT32_MAX - 1));
@@ -546,7 +546,9 @@ __global__ __launch_bounds__(1024) void k_plan_explicit(PlanDevArgs a) { plan_ex
 // the input spectra + zero fill (the other M + 1 workgroups).  The two planner kernels used to run serially ahead of the spectra kernel, which needs
 // nothing of theirs: 4.5 + 15 us + two boundaries on the critical path of convolve_moving_receiver (SonicSim_moving.py:63-96).  Workgroups are
 // dispatched in index order, so when the planner spins every workgroup it waits for is already resident: no deadlock.  (Two streams instead cost
-// two cross-queue dependencies of ~8 us each: measured slower than the serial form, profiles/r06o.)
+// two cross-queue dependencies of ~8 us each: measured slower than the serial form, profiles/r06o.)  The hand-off of the bounds uses write-through
+// stores, a drain and agent-scope loads -- NOT a release fence, which on this chip writes the XCD's dirty L2 back and cost 20-40 us beside the
+// spectra workgroups' 38 MB of stores (profiles/r06p); with it the launch takes ~23 us where the two launches took 27 + a boundary (profiles/r06aa).
 constexpr int FRONT_MMT = 8;
 template <bool PLAN> __global__ __launch_bounds__(512, PLAN ? 1 : 2) void k_front_explicit(const float* __restrict__ x, int64_t T, const c32* __restrict__ consts, c32* __restrict__ Xs, int M,
                                                            float* __restrict__ yzero, int64_t nzero, int* __restrict__ counter, int ncnt, int cnt_init,
@@ -575,26 +577,32 @@ template <bool PLAN> __global__ __launch_bounds__(512, PLAN ? 1 : 2) void k_fron
             }
             if (lane == 0) {
                 const long long big = 0x7fffffffLL;          // clamp into int32 so out-of-range values are still detected
-                bmin[tile] = (int32_t)(lo < -big ? -big : (lo > big ? big : lo));
-                bmax[tile] = (int32_t)(hi < -big ? -big : (hi > big ? big : hi));
+                const int32_t vlo = (int32_t)(lo < -big ? -big : (lo > big ? big : lo)), vhi = (int32_t)(hi < -big ? -big : (hi > big ? big : hi));
+                if constexpr (PLAN) {
+                    // write-through stores + a drain instead of a release fence: an agent-scope RELEASE on this chip writes the XCD's dirty L2 lines back, and
+                    // the spectra workgroups have 38 MB of stores in flight beside us (one fence per workgroup: 46 us for this launch; per wave: 67).  The
+                    // planner reads the bounds with agent-scope loads (ld_agent), so no cache holds a stale copy -- the pattern of k_rir_synth's peak slots.
+                    __hip_atomic_store(bmin + tile, vlo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(bmax + tile, vhi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                } else {
+                    bmin[tile] = vlo;
+                    bmax[tile] = vhi;
+                }
             }
-            if constexpr (PLAN) __threadfence();             // this wave's two stores are visible device-wide before the workgroup's arrival is counted (an
-                                                             // agent-scope release writes the XCD's dirty L2 lines back: with the spectra kernel's 38 MB
-                                                             // of stores in flight every fence costs microseconds -- why the fused form is slower)
         }
         if constexpr (PLAN) {
             __syncthreads();
-            if (tid == 0) __hip_atomic_fetch_add(mm_done, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid == 0) __hip_atomic_fetch_add(mm_done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         return;
     }
     if (PLAN && b == n_mm) {
         if (tid == 0) {
-            while (__hip_atomic_load(mm_done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < n_mm) __builtin_amdgcn_s_sleep(8);
+            while (__hip_atomic_load(mm_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < n_mm) __builtin_amdgcn_s_sleep(4);
             __hip_atomic_store(mm_done, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // (the next call on this lane starts from zero)
         }
         __syncthreads();
-        __threadfence();
         if constexpr (PLAN) plan_explicit_body(pa);
         return;
     }
@@ -2467,8 +2475,9 @@ int render(int mode, const float* x, int64_t T, const float* bank, int32_t P, in
             if (g13 || g14) {
                 if (dev_plan) {
                     const int n_mm = (int)((nfine + FRONT_MMT - 1) / FRONT_MMT);
-                    static const int front_fused = knob("SS_FRONT_FUSED") ? atoi(knob("SS_FRONT_FUSED")) : 0;
-                    if (front_fused) {        // (tuning build: the planner as one more workgroup of this launch -- measured SLOWER, LAB round 6)
+                    static const int front_fused = knob("SS_FRONT_FUSED") ? atoi(knob("SS_FRONT_FUSED")) : 1;
+                    if (front_fused) {        // the planner as one more workgroup of this launch, waiting for the tile-bound workgroups' arrivals (default since the
+                                              // hand-off needs no release fence: write-through stores + agent-scope loads; SS_FRONT_FUSED=0 in the tuning build: two launches)
                         hipLaunchKernelGGL(k_front_explicit<true>, dim3((unsigned)(n_mm + 1 + M + 1)), dim3(NT13), 0, stream, dx, T, (const c32*)c->consts13, (c32*)c->ws[WS_XS], M,
                                            dy, (int64_t)C * T, qgroups ? (int*)c->ws[WS_CNT] : (int*)nullptr, qgroups + 1, qinit, xdiv, didx,
                                            (int32_t*)c->ws[WS_BMIN], (int32_t*)c->ws[WS_BMAX], n_mm, (int*)c->ws[WS_STATUS] + 7, pa);

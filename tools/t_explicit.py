@@ -5,6 +5,10 @@ import sys, time, json
 import numpy as np, torch
 sys.path.insert(0, ".")
 from oracle import moving as O
+import os as _os
+from sonicsim_amd import _lib as _sslib
+if _os.environ.get('BENCH_LIB'):
+    _sslib.use_library(_os.environ['BENCH_LIB'])
 from sonicsim_amd import ops, synth
 ops.init(0)
 dev = torch.device("cuda:0")
