@@ -230,11 +230,12 @@ __global__ __launch_bounds__(256) void k_idx_minmax(const int64_t* __restrict__ 
 }
 
 #ifdef SS_DEBUG_CLK
-__device__ unsigned long long g_dbg_clk[8][2][256];
-#define DBG_CLK(kid, which) do { if (threadIdx.x == 0) { const int wg_ = blockIdx.x + gridDim.x * blockIdx.y; if (wg_ < 256) g_dbg_clk[kid][which][wg_] = wall_clock64(); } } while (0)
+__device__ unsigned long long g_dbg_clk[12][2][256];
+#define DBG_CLK_T(kid, which, thr) do { if (threadIdx.x == (thr)) { const int wg_ = blockIdx.x + gridDim.x * blockIdx.y; if (wg_ < 256) g_dbg_clk[kid][which][wg_] = wall_clock64(); } } while (0)
 #else
-#define DBG_CLK(kid, which) do {} while (0)
+#define DBG_CLK_T(kid, which, thr) do {} while (0)
 #endif
+#define DBG_CLK(kid, which) DBG_CLK_T(kid, which, 0)
 // ---------------------------------------------------------------------------------------------
 // Device-side planner of the explicit (idx, w) schedule for the assembly engine (SS_FLAG_ASYNC_PLAN): the task list of plan.h's
 // build_plan + merge_lpt_xcd, produced on the stream from k_idx_minmax's tile bounds -- no copy to the host, no synchronisation.
@@ -1315,11 +1316,22 @@ __global__ __launch_bounds__(256) void k_resample(const float* __restrict__ x, i
 // ---- K-weighting (row U): two cascaded biquads, transposed direct form II (scipy.signal.lfilter),
 // float64 state.  Chunk-parallel: (1) zero-state run per chunk -> end state, (2) sequential state
 // propagation across chunks with the 4x4 chunk transition matrix, (3) re-run from the true state.
-struct KwCoef {
-    double b[2][3], a[2][3];
-    double Mp[13][16];   // Mp[i] = (state transition over one full chunk) ^ (2^i), row-major 4x4
-    double W[64][4];     // zero-state END state of a full chunk as a linear map of its samples: z = sum_t W[t] * x[t]
+// Row U's two biquads in DELTA form (round 6).  With a1 = -2 + d1, a2 = 1 - d2 the direct-form-II recurrence w[n] = x[n] - a1 w[n-1] - a2 w[n-2]
+// becomes, in the states w1 = w[n-1] and d = w[n-1] - w[n-2],
+//     d' = x + d - d2 d - eps w1,   w1' = w1 + d',   y = beta w1 + b0 d' - b2 d        (eps = A(1) = 1 + a1 + a2, beta = B(1) = b0 + b1 + b2)
+// i.e. the SMALL quantities (K-weighting's high-pass has eps = 2.5e-5, d2 = 0.01 at 48 kHz) are the coefficients, each held to full relative
+// precision.  In float64 this equals SciPy's lfilter to 1e-14 in the loudness; in FLOAT32 it stays within 4e-6 dB of it over noise, tones down to
+// 50 Hz, brown noise and a DC offset of 0.3 at 8 / 16 / 44.1 / 48 kHz (2e-7 dB at 16 kHz), where the textbook forms with float32-rounded
+// a1, a2 are off by up to 5e-4 in |H|^2 below 100 Hz (tools/lab/r06_kw_f32.py).  7 operations per stage, a dependent chain of 3.
+template <class R>
+struct KwTabT {
+    R b[2][3], a[2][3];   // the normalised biquads as given (host-side identity of the table set)
+    R c[2][6];            // per stage: d2, eps, beta, b0, b2, (pad)
+    R Mp[13][16];         // Mp[i] = (state transition over one full chunk) ^ (2^i), row-major 4x4; state = (w1, d) of stage 1, (w1, d) of stage 2
+    R W[64][4];           // zero-state END state of a full chunk as a linear map of its samples: z = sum_t W[t] * x[t]
 };
+using KwCoef = KwTabT<double>;
+using KwCoefF = KwTabT<float>;
 static_assert(sizeof(((KwCoef*)0)->W) == 64 * 4 * 8, "W is [KW_CHUNK][4]");
 constexpr int KW_CHUNK = 64;     // samples per thread in the sample-level passes (divides the 0.1 s block step at 16 kHz)
 constexpr int KW_ROW = KW_CHUNK + 4;   // floats per LDS row of the fused kernel: 16-lane groups of b128 accesses hit distinct banks
@@ -1327,18 +1339,25 @@ constexpr int KW_SER = 8;        // chunks each scan thread walks serially
 constexpr int KW_TILE = 512;     // threads of the scan workgroup: one tile = KW_TILE * KW_SER chunks
 static_assert(KW_SER == 8 && KW_TILE == 512, "the scan's power indices (Mp[3+b], Mp[9+b], Mp[12]) assume 8 chunks/thread, 8 waves");
 
-// (round 6: written as explicit FMA chains -- 5 float64 operations per biquad step where the compiler's own contraction of the textbook form
-//  left 7-8; the recurrence is the kernel's instruction-issue bound.  Rounding differs from SciPy's unfused lfilter in the last bit, like before.)
-__device__ __forceinline__ double kw_step(const KwCoef& k, double s[4], double xin) {
-    const double y1 = fma(k.b[0][0], xin, s[0]);
-    s[0] = fma(k.b[0][1], xin, fma(-k.a[0][1], y1, s[1]));
-    s[1] = fma(k.b[0][2], xin, -k.a[0][2] * y1);
-    const double y2 = fma(k.b[1][0], y1, s[2]);
-    s[2] = fma(k.b[1][1], y1, fma(-k.a[1][1], y2, s[3]));
-    s[3] = fma(k.b[1][2], y1, -k.a[1][2] * y2);
-    return y2;
+template <class R>
+__host__ __device__ __forceinline__ R kw_stage(const R* __restrict__ c, R& w1, R& d, R x) {
+    R t = x + d;
+    t = fma(-c[1], w1, t);
+    const R dn = fma(-c[0], d, t);
+    R y = c[2] * w1;
+    y = fma(c[3], dn, y);
+    y = fma(-c[4], d, y);
+    w1 += dn;
+    d = dn;
+    return y;
 }
-__device__ __forceinline__ void kw_matvec(const double* M, const double s[4], double o[4]) {
+template <class R>
+__host__ __device__ __forceinline__ R kw_step(const KwTabT<R>& k, R s[4], R xin) {
+    const R y1 = kw_stage<R>(k.c[0], s[0], s[1], xin);
+    return kw_stage<R>(k.c[1], s[2], s[3], y1);
+}
+template <class R>
+__device__ __forceinline__ void kw_matvec(const R* M, const R s[4], R o[4]) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) o[r] = M[r * 4 + 0] * s[0] + M[r * 4 + 1] * s[1] + M[r * 4 + 2] * s[2] + M[r * 4 + 3] * s[3];
 }
@@ -1360,7 +1379,8 @@ __device__ __forceinline__ void kw_walk(const float* __restrict__ a, int64_t t0,
 
 // zero-state end state of one chunk by its FIR form: 4 independent dot products (256 FMAs, no recurrence) instead of 64
 // dependent biquad steps (~700 float64 ops).  A short last chunk of n samples uses the rows W[64-n..63].
-__device__ __forceinline__ void kw_endstate(const float* __restrict__ a, int64_t t0, int64_t t1, int64_t st, const KwCoef& k, double v[4]) {
+template <class R>
+__device__ __forceinline__ void kw_endstate(const float* __restrict__ a, int64_t t0, int64_t t1, int64_t st, const KwTabT<R>& k, R v[4]) {
     if (st == 1 && t1 - t0 == KW_CHUNK && (((uintptr_t)(a + t0)) & 15) == 0) {
         const float4* p = (const float4*)(a + t0);
         float4 q[KW_CHUNK / 4];
@@ -1368,7 +1388,7 @@ __device__ __forceinline__ void kw_endstate(const float* __restrict__ a, int64_t
         for (int i = 0; i < KW_CHUNK / 4; ++i) q[i] = p[i];
 #pragma unroll
         for (int i = 0; i < KW_CHUNK / 4; ++i) {
-            const double x0 = (double)q[i].x, x1 = (double)q[i].y, x2 = (double)q[i].z, x3 = (double)q[i].w;
+            const R x0 = (R)q[i].x, x1 = (R)q[i].y, x2 = (R)q[i].z, x3 = (R)q[i].w;
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 v[r] = fma(k.W[4 * i + 3][r], x3, fma(k.W[4 * i + 2][r], x2, fma(k.W[4 * i + 1][r], x1, fma(k.W[4 * i][r], x0, v[r]))));
@@ -1376,8 +1396,8 @@ __device__ __forceinline__ void kw_endstate(const float* __restrict__ a, int64_t
     } else {
         const int off = KW_CHUNK - (int)(t1 - t0);
         for (int64_t t = t0; t < t1; ++t) {
-            const double x = (double)a[t * st];
-            const double* w = k.W[off + (int)(t - t0)];
+            const R x = (R)a[t * st];
+            const R* w = k.W[off + (int)(t - t0)];
             v[0] += w[0] * x; v[1] += w[1] * x; v[2] += w[2] * x; v[3] += w[3] * x;
         }
     }
@@ -1537,25 +1557,21 @@ __global__ __launch_bounds__(KW_TILE) void k_kw_scan_carry(const KwCoef* __restr
 // float64 resolution.  Phase 1: zero-state walk -> chunk end state.  Phase 2: Hillis-Steele inside each wave (M^1..M^32) and
 // over the wave totals (M^64..), chunk start = previous lane's prefix + M^lane * (wave carry-in).  Phase 3: the new chunks
 // walk again from their start state and keep their energy (+ the start state, for k_block_power_chunks' edge chunks).
-template <int NT>
+// R = float (the product's form since round 6: the delta-form recurrence keeps float32 within ~1e-6 dB of the float64 walk, see KwTabT) or double
+// (the round-2..5 form; tuning knob SS_KW_F64, and what the exact multi-launch path below still computes in).  The chunk energies and the start
+// states leave the kernel as float64 either way: block powers, gating and the gain are float64 sums (k_block_power_chunks, k_gate).
+template <int NT, class R>
 __global__ __launch_bounds__(NT) void k_kw_fused(const float* __restrict__ audio, int64_t T, int64_t st, int64_t sc,
-                                                 const KwCoef* __restrict__ kp, const double* __restrict__ plane /*[64][16] = M^lane*/,
+                                                 const KwTabT<R>* __restrict__ kp, const R* __restrict__ plane /*[64][16] = M^lane*/,
                                                  int nchunks, int H, double* __restrict__ states, double* __restrict__ energy) {
     constexpr int NW = NT / 64;
     __shared__ float xs[NW][64][KW_ROW];              // the wave's 64 chunks, one padded row per chunk
-    __shared__ double wt[NW][4];
-    __shared__ double mp[10][16];
-    const KwCoef& k = *kp;
+    __shared__ R wt[NW][4];
+    __shared__ R mp[10][16];
+    const KwTabT<R>& k = *kp;
     const int c = blockIdx.y, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int ch = blockIdx.x * (NT - H) - H + tid;
     if (tid < 160) (&mp[0][0])[tid] = (&kp->Mp[0][0])[tid];
-    double P[16];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const double2 q = ((const double2*)(plane + lane * 16))[i];
-        P[2 * i] = q.x;
-        P[2 * i + 1] = q.y;
-    }
     const bool live = ch >= 0 && ch < nchunks;
     const float* a = audio + c * sc;
     // the wave's 64 chunks are 16 KiB of contiguous samples: fetch them with fully coalesced 16-byte loads and hand each
@@ -1574,63 +1590,212 @@ __global__ __launch_bounds__(NT) void k_kw_fused(const float* __restrict__ audio
     const float* row = &xs[w][lane][0];
     const int64_t t0 = (int64_t)ch * KW_CHUNK;
     const int64_t t1 = t0 + KW_CHUNK < T ? t0 + KW_CHUNK : T;
-    double v[4] = {0, 0, 0, 0}, m[4], u[4];
+    R v[4] = {0, 0, 0, 0}, m[4], u[4];
     DBG_CLK(0, 0);
+    DBG_CLK_T(8, 0, 64);
     __syncthreads();
+    DBG_CLK_T(8, 1, 64);
     if (live) {
-        if (fast) kw_endstate(row, 0, KW_CHUNK, 1, k, v);
-        else kw_endstate(a, t0, t1, st, k, v);
+        if (fast) kw_endstate<R>(row, 0, KW_CHUNK, 1, k, v);
+        else kw_endstate<R>(a, t0, t1, st, k, v);
     }
     DBG_CLK(1, 0);
     DBG_CLK(1, 1);
+    DBG_CLK_T(9, 0, 64);
 #pragma unroll
     for (int b = 0; b < 6; ++b) {
         const int d = 1 << b;
 #pragma unroll
         for (int r = 0; r < 4; ++r) u[r] = __shfl_up(v[r], d, 64);
-        kw_matvec(mp[b], u, m);
+        kw_matvec<R>(mp[b], u, m);
         if (lane >= d) { v[0] += m[0]; v[1] += m[1]; v[2] += m[2]; v[3] += m[3]; }
     }
     if (lane == 63) { wt[w][0] = v[0]; wt[w][1] = v[1]; wt[w][2] = v[2]; wt[w][3] = v[3]; }
     __syncthreads();
     if (w == 0) {
-        double t[4] = {0, 0, 0, 0};
+        R t[4] = {0, 0, 0, 0};
         if (lane < NW) { t[0] = wt[lane][0]; t[1] = wt[lane][1]; t[2] = wt[lane][2]; t[3] = wt[lane][3]; }
 #pragma unroll
         for (int b = 0; (1 << b) < NW; ++b) {
             const int d = 1 << b;
 #pragma unroll
             for (int r = 0; r < 4; ++r) u[r] = __shfl_up(t[r], d, 64);
-            kw_matvec(mp[6 + b], u, m);
+            kw_matvec<R>(mp[6 + b], u, m);
             if (lane >= d) { t[0] += m[0]; t[1] += m[1]; t[2] += m[2]; t[3] += m[3]; }
         }
         if (lane < NW) { wt[lane][0] = t[0]; wt[lane][1] = t[1]; wt[lane][2] = t[2]; wt[lane][3] = t[3]; }   // END state of wave `lane`
     }
     __syncthreads();
-    double cw[4], S[4];
+    R cw[4], S[4], P[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) P[i] = plane[lane * 16 + i];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        cw[r] = w == 0 ? 0.0 : wt[w > 0 ? w - 1 : 0][r];
+        cw[r] = w == 0 ? (R)0 : wt[w > 0 ? w - 1 : 0][r];
         u[r] = __shfl_up(v[r], 1, 64);
-        if (lane == 0) u[r] = 0.0;
+        if (lane == 0) u[r] = (R)0;
     }
-    kw_matvec(P, cw, m);
+    kw_matvec<R>(P, cw, m);
     S[0] = u[0] + m[0]; S[1] = u[1] + m[1]; S[2] = u[2] + m[2]; S[3] = u[3] + m[3];
     DBG_CLK(7, 0);
+    DBG_CLK_T(9, 1, 64);
     if (live && tid >= H) {
         double2* q = (double2*)(states + ((int64_t)c * nchunks + ch) * 4);
-        q[0] = make_double2(S[0], S[1]);
-        q[1] = make_double2(S[2], S[3]);
-        double e = 0.0;
+        q[0] = make_double2((double)S[0], (double)S[1]);
+        q[1] = make_double2((double)S[2], (double)S[3]);
+        R e = 0;
         auto f = [&](float x) {
-            const double y = kw_step(k, S, (double)x);
-            e += y * y;
+            const R y = kw_step<R>(k, S, (R)x);
+            e = fma(y, y, e);
         };
         if (fast) kw_walk(row, 0, KW_CHUNK, 1, f);
         else kw_walk(a, t0, t1, st, f);
-        energy[(int64_t)c * nchunks + ch] = e;
+        energy[(int64_t)c * nchunks + ch] = (double)e;
     }
     DBG_CLK(0, 1);
+    DBG_CLK_T(10, 0, 64);
+}
+// The float32 form of k_kw_fused with the thread's chunk held in REGISTERS: the wave's 16 KiB arrive as 16 float4 per lane (quarter q of 16 chunks per
+// load: 64 contiguous bytes per 4 lanes), and four rounds through a 5 KiB per-wave transit buffer turn them, in place, into the lane's own chunk (round q:
+// write the four registers of quarter q, read back samples 16q .. 16q+15 of chunk `lane`; rows of 20 floats: conflict-free b128 on both sides).  LDS per
+// workgroup 21 KiB instead of 70 (the staged chunks), 4 waves per SIMD instead of 2, no barrier around the staging (the transit buffer is the wave's own),
+// and neither walk reads LDS.  Same arithmetic and the same order of operations as k_kw_fused<NT, float>: identical bits (tests/test_gpu_aux.py).
+constexpr int KW_TROW = 20;
+typedef float kw_v4f __attribute__((ext_vector_type(4)));
+// HPS: the second stage's numerator is a scaled double difference b = g (1, -2, 1) -- BS.1770's high-pass as pyloudnorm generates it (beta = 0, b0 = b2 = g):
+// y = g (d' - d).  The walk keeps d' - d (three operations fewer per sample than the general form) and the chunk energy is scaled by g^2 in float64 at the end.
+template <bool HPS>
+__device__ __forceinline__ float kw_step32(const KwCoefF& k, float s[4], float xin) {
+    const float y1 = kw_stage<float>(k.c[0], s[0], s[1], xin);
+    if (!HPS) return kw_stage<float>(k.c[1], s[2], s[3], y1);
+    float t = y1 + s[3];
+    t = fma(-k.c[1][1], s[2], t);
+    const float dn = fma(-k.c[1][0], s[3], t);
+    const float y = dn - s[3];
+    s[2] += dn;
+    s[3] = dn;
+    return y;
+}
+// The end states are a (4 x 64) x (64 x 64 chunks) product whose columns are the lanes: 64 rank-one updates v_mfma_f32_4x4x1 (16 blocks of 4 lanes: A = the
+// lane's W[t][lane & 3], B = the lane's own sample t, D = the lane's four state components) -- on the matrix pipe, beside the other waves' walks on the VALU,
+// with the coefficients from a 1 KiB LDS table instead of 16 dependent scalar-cache round trips (1.6 -> 0.5 us per workgroup, profiles/r06ag).
+template <int NT, bool HPS>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_kw_fused32(const float* __restrict__ audio, int64_t T, int64_t st, int64_t sc,
+                                                   const KwCoefF* __restrict__ kp, const float* __restrict__ plane /*[64][16] = M^lane*/,
+                                                   int nchunks, int H, double* __restrict__ states, double* __restrict__ energy, double g2 /* HPS: b0^2 of stage 2 */) {
+    constexpr int NW = NT / 64;
+    __shared__ float xt[NW][64 * KW_TROW];
+    __shared__ float wt[NW][4];
+    __shared__ float mp[10][16];
+    __shared__ float wtab[4][KW_CHUNK];                // W transposed: wtab[r][t]
+    const KwCoefF& k = *kp;
+    const int c = blockIdx.y, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int ch = blockIdx.x * (NT - H) - H + tid;
+    if (tid < 160) (&mp[0][0])[tid] = (&kp->Mp[0][0])[tid];
+    if (tid < 256) wtab[tid & 3][tid >> 2] = (&kp->W[0][0])[tid];
+    const bool live = ch >= 0 && ch < nchunks;
+    const float* a = audio + c * sc;
+    const int chw = ch - lane;
+    const int64_t tw = (int64_t)chw * KW_CHUNK;
+    const bool fast = st == 1 && chw >= 0 && tw + 64 * KW_CHUNK <= T && (((uintptr_t)(a + tw)) & 15) == 0;
+    float4 X[16];
+    if (fast) {
+        const float4* g = (const float4*)(a + tw) + (lane >> 2) * 16 + (lane & 3);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) X[4 * q + j] = g[(16 * j) * 16 + 4 * q];
+        float* tr = &xt[w][0];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) *(float4*)&tr[(16 * j + (lane >> 2)) * KW_TROW + (lane & 3) * 4] = X[4 * q + j];
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int i = 0; i < 4; ++i) X[4 * q + i] = *(const float4*)&tr[lane * KW_TROW + 4 * i];
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    const int64_t t0 = (int64_t)ch * KW_CHUNK;
+    const int64_t t1 = t0 + KW_CHUNK < T ? t0 + KW_CHUNK : T;
+    float v[4] = {0, 0, 0, 0}, m[4], u[4];
+    DBG_CLK(0, 0);
+    DBG_CLK_T(8, 0, 64);
+    __syncthreads();                                  // (mp[], wtab[])
+    DBG_CLK_T(8, 1, 64);
+    if (fast) {
+        kw_v4f d0 = {0, 0, 0, 0}, d1 = {0, 0, 0, 0};
+        const float* wl = &wtab[lane & 3][0];
+#pragma unroll
+        for (int i = 0; i < KW_CHUNK / 4; ++i) {
+            const float4 wv = *(const float4*)&wl[4 * i];
+            d0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wv.x, X[i].x, d0, 0, 0, 0);
+            d1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wv.y, X[i].y, d1, 0, 0, 0);
+            d0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wv.z, X[i].z, d0, 0, 0, 0);
+            d1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wv.w, X[i].w, d1, 0, 0, 0);
+        }
+        v[0] = d0[0] + d1[0]; v[1] = d0[1] + d1[1]; v[2] = d0[2] + d1[2]; v[3] = d0[3] + d1[3];
+    } else if (live) kw_endstate<float>(a, t0, t1, st, k, v);
+    DBG_CLK(1, 0);
+    DBG_CLK(1, 1);
+    DBG_CLK_T(9, 0, 64);
+#pragma unroll
+    for (int b = 0; b < 6; ++b) {
+        const int d = 1 << b;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) u[r] = __shfl_up(v[r], d, 64);
+        kw_matvec<float>(mp[b], u, m);
+        if (lane >= d) { v[0] += m[0]; v[1] += m[1]; v[2] += m[2]; v[3] += m[3]; }
+    }
+    if (lane == 63) { wt[w][0] = v[0]; wt[w][1] = v[1]; wt[w][2] = v[2]; wt[w][3] = v[3]; }
+    __syncthreads();
+    if (w == 0) {
+        float t[4] = {0, 0, 0, 0};
+        if (lane < NW) { t[0] = wt[lane][0]; t[1] = wt[lane][1]; t[2] = wt[lane][2]; t[3] = wt[lane][3]; }
+#pragma unroll
+        for (int b = 0; (1 << b) < NW; ++b) {
+            const int d = 1 << b;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) u[r] = __shfl_up(t[r], d, 64);
+            kw_matvec<float>(mp[6 + b], u, m);
+            if (lane >= d) { t[0] += m[0]; t[1] += m[1]; t[2] += m[2]; t[3] += m[3]; }
+        }
+        if (lane < NW) { wt[lane][0] = t[0]; wt[lane][1] = t[1]; wt[lane][2] = t[2]; wt[lane][3] = t[3]; }   // END state of wave `lane`
+    }
+    __syncthreads();
+    float cw[4], S[4], P[16];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float4 p4 = ((const float4*)(plane + lane * 16))[i];
+        P[4 * i] = p4.x; P[4 * i + 1] = p4.y; P[4 * i + 2] = p4.z; P[4 * i + 3] = p4.w;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        cw[r] = w == 0 ? 0.f : wt[w > 0 ? w - 1 : 0][r];
+        u[r] = __shfl_up(v[r], 1, 64);
+        if (lane == 0) u[r] = 0.f;
+    }
+    kw_matvec<float>(P, cw, m);
+    S[0] = u[0] + m[0]; S[1] = u[1] + m[1]; S[2] = u[2] + m[2]; S[3] = u[3] + m[3];
+    DBG_CLK(7, 0);
+    DBG_CLK_T(9, 1, 64);
+    if (live && tid >= H) {
+        double2* q = (double2*)(states + ((int64_t)c * nchunks + ch) * 4);
+        q[0] = make_double2((double)S[0], (double)S[1]);
+        q[1] = make_double2((double)S[2], (double)S[3]);
+        float e = 0;
+        auto f = [&](float x) {
+            const float y = kw_step32<HPS>(k, S, x);
+            e = fma(y, y, e);
+        };
+        if (fast) {
+#pragma unroll
+            for (int i = 0; i < KW_CHUNK / 4; ++i) { f(X[i].x); f(X[i].y); f(X[i].z); f(X[i].w); }
+        } else kw_walk(a, t0, t1, st, f);
+        energy[(int64_t)c * nchunks + ch] = HPS ? (double)e * g2 : (double)e;
+    }
+    DBG_CLK(0, 1);
+    DBG_CLK_T(10, 0, 64);
 }
 // pass 3: re-run every chunk from its true start state and keep only the chunk's K-weighted energy (float64): the gating
 // blocks are sums of whole chunks plus two partial edge chunks (k_block_power_chunks), so the filtered signal is never stored
@@ -3538,32 +3703,25 @@ static int kw_setup(const double* coef, KwCoef& k) {
         if (a0 == 0.0) return fail(SS_EINVAL, "a0 == 0");
         for (int i = 0; i < 3; ++i) { k.b[s][i] = coef[s * 6 + i] / a0; k.a[s][i] = coef[s * 6 + 3 + i] / a0; }
     }
+    for (int st = 0; st < 2; ++st) {                    // delta form (KwTabT): d2 = 1 - a2, eps = A(1), beta = B(1), b0, b2
+        k.c[st][0] = 1.0 - k.a[st][2];
+        k.c[st][1] = (1.0 + k.a[st][1]) + k.a[st][2];
+        k.c[st][2] = (k.b[st][0] + k.b[st][1]) + k.b[st][2];
+        k.c[st][3] = k.b[st][0];
+        k.c[st][4] = k.b[st][2];
+        k.c[st][5] = 0.0;
+    }
     // chunk transition matrix: zero-input response of the cascade from the 4 unit states
     for (int u = 0; u < 4; ++u) {
         double s[4] = {0, 0, 0, 0};
         s[u] = 1.0;
-        for (int t = 0; t < KW_CHUNK; ++t) {
-            const double y1 = s[0];
-            s[0] = -k.a[0][1] * y1 + s[1];
-            s[1] = -k.a[0][2] * y1;
-            const double y2 = k.b[1][0] * y1 + s[2];
-            s[2] = k.b[1][1] * y1 - k.a[1][1] * y2 + s[3];
-            s[3] = k.b[1][2] * y1 - k.a[1][2] * y2;
-        }
+        for (int t = 0; t < KW_CHUNK; ++t) kw_step<double>(k, s, 0.0);
         for (int r = 0; r < 4; ++r) k.Mp[0][r * 4 + u] = s[r];
     }
     // W[t] = end state of a chunk whose only non-zero sample is x[t] = 1
     for (int t = 0; t < KW_CHUNK; ++t) {
         double s[4] = {0, 0, 0, 0};
-        for (int u = t; u < KW_CHUNK; ++u) {
-            const double xin = u == t ? 1.0 : 0.0;
-            const double y1 = k.b[0][0] * xin + s[0];
-            s[0] = k.b[0][1] * xin - k.a[0][1] * y1 + s[1];
-            s[1] = k.b[0][2] * xin - k.a[0][2] * y1;
-            const double y2 = k.b[1][0] * y1 + s[2];
-            s[2] = k.b[1][1] * y1 - k.a[1][1] * y2 + s[3];
-            s[3] = k.b[1][2] * y1 - k.a[1][2] * y2;
-        }
+        for (int u = t; u < KW_CHUNK; ++u) kw_step<double>(k, s, u == t ? 1.0 : 0.0);
         for (int r = 0; r < 4; ++r) k.W[t][r] = s[r];
     }
     for (int i = 1; i < 13; ++i)                        // Mp[i] = Mp[i-1]^2
@@ -3607,7 +3765,9 @@ static int kw_block_power_dev(Ctx* c, const float* da, int64_t T, int32_t C, int
     // per-lane carry powers (M^KW_SER)^lane of the scan: uploaded when the coefficients change (i.e. once per sample rate)
     const int ntiles = (nchunks + KW_TILE * KW_SER - 1) / (KW_TILE * KW_SER);
     const size_t koff = (sizeof(KwCoef) + 255) & ~(size_t)255;      // ws[WS_KWP] = [KwCoef][72 4x4 carry-power matrices]
-    const size_t ptab_bytes = koff + sizeof(double) * (72 + 64) * 16;   // + [64] M^lane for the fused kernel
+    const size_t foff = koff + sizeof(double) * (72 + 64) * 16;         // + [64] M^lane for the fused kernel
+    const size_t fpoff = foff + ((sizeof(KwCoefF) + 255) & ~(size_t)255);                        // float32 copies for k_kw_fused<., float>: [KwCoefF][64 x M^lane]
+    const size_t ptab_bytes = fpoff + sizeof(float) * 64 * 16;
     if ((rc = ws_ensure(c, WS_KWP, ptab_bytes))) return rc;                                       // fixed size: never reallocated
     if ((rc = ws_ensure(c, WS_KWT, sizeof(double) * 4 * (size_t)C * ntiles))) return rc;           // tile totals
     if (memcmp(c->kw_cached, k.b, sizeof(c->kw_cached)) != 0 || c->kw_cached_dev != c->ws[WS_KWP]) {
@@ -3641,6 +3801,14 @@ static int kw_block_power_dev(Ctx* c, const float* da, int64_t T, int32_t C, int
                     for (int m = 0; m < 4; ++m) acc += lt[(l - 1) * 16 + r * 4 + m] * k.Mp[0][m * 4 + q];
                     lt[l * 16 + r * 4 + q] = acc;
                 }
+        {                                                // the float32 table set: every entry the float64 one's nearest float
+            KwCoefF* kf = (KwCoefF*)((char*)pin->host + foff);
+            const double* src = (const double*)&k;
+            float* dst = (float*)kf;
+            for (size_t i = 0; i < sizeof(KwCoef) / sizeof(double); ++i) dst[i] = (float)src[i];
+            float* lf = (float*)((char*)pin->host + fpoff);
+            for (int i = 0; i < 64 * 16; ++i) lf[i] = (float)lt[i];
+        }
         HIPCHK(hipMemcpyAsync(c->ws[WS_KWP], pin->host, ptab_bytes, hipMemcpyHostToDevice, stream));
         HIPCHK(hipEventRecord(pin->ev, stream));
         pin->pending = true;
@@ -3653,24 +3821,37 @@ static int kw_block_power_dev(Ctx* c, const float* da, int64_t T, int32_t C, int
     const KwCoef* kd = (const KwCoef*)c->ws[WS_KWP];
     double* ptab = (double*)((char*)c->ws[WS_KWP] + koff);
     double* tot = (double*)c->ws[WS_KWT];
-    // history the fused kernel needs: the first power of two H with |M^H| <= 1e-20 entrywise
+    // history the fused kernel needs: the first power of two H with |M^H| <= 1e-20 entrywise (1e-12 for the float32 walk, whose states carry 6e-8)
+    static const int kw_f64 = knob("SS_KW_F64") ? atoi(knob("SS_KW_F64")) : 0;      // (tuning build: the float64 walk of rounds 2-5)
     int hp = 0;
     for (; hp < 10; ++hp) {
         double mx = 0;
         for (int i = 0; i < 16; ++i) mx = std::max(mx, std::fabs(k.Mp[hp][i]));
-        if (mx <= 1e-20) break;
+        if (mx <= (kw_f64 ? 1e-20 : 1e-12)) break;
     }
     const char* fe = getenv("SS_KW_EXACT");        // test switch (the only environment variable the product library reads): force the exact multi-launch scan
     const bool force_exact = fe && atoi(fe);
     if (hp <= 8 && !force_exact) {
         const int H = 1 << hp;
         const double* plane = ptab + 72 * 16;
-        if (H <= 64) {
-            const int nt = 256, tiles = (nchunks + (nt - H) - 1) / (nt - H);
-            hipLaunchKernelGGL(k_kw_fused<256>, dim3(tiles, C), dim3(nt), 0, stream, da, T, st, sc, kd, plane, nchunks, H, states, energy);
+        const KwCoefF* kf = (const KwCoefF*)((char*)c->ws[WS_KWP] + foff);
+        const float* planef = (const float*)((char*)c->ws[WS_KWP] + fpoff);
+        const int nt = H <= 64 ? 256 : 512, tiles = (nchunks + (nt - H) - 1) / (nt - H);
+        if (kw_f64) {
+            if (nt == 256) hipLaunchKernelGGL((k_kw_fused<256, double>), dim3(tiles, C), dim3(nt), 0, stream, da, T, st, sc, kd, plane, nchunks, H, states, energy);
+            else hipLaunchKernelGGL((k_kw_fused<512, double>), dim3(tiles, C), dim3(nt), 0, stream, da, T, st, sc, kd, plane, nchunks, H, states, energy);
         } else {
-            const int nt = 512, tiles = (nchunks + (nt - H) - 1) / (nt - H);
-            hipLaunchKernelGGL(k_kw_fused<512>, dim3(tiles, C), dim3(nt), 0, stream, da, T, st, sc, kd, plane, nchunks, H, states, energy);
+            static const int kw_lds = knob("SS_KW_LDS") ? atoi(knob("SS_KW_LDS")) : 0;  // (tuning build: the float32 walk with the chunks staged in LDS)
+            if (kw_lds) {
+                if (nt == 256) hipLaunchKernelGGL((k_kw_fused<256, float>), dim3(tiles, C), dim3(nt), 0, stream, da, T, st, sc, kf, planef, nchunks, H, states, energy);
+                else hipLaunchKernelGGL((k_kw_fused<512, float>), dim3(tiles, C), dim3(nt), 0, stream, da, T, st, sc, kf, planef, nchunks, H, states, energy);
+            } else {
+                const bool hps = k.c[1][2] == 0.0 && k.c[1][3] == k.c[1][4];                    // BS.1770's high-pass: b = g (1, -2, 1)
+                static const int kw_nt = knob("SS_KW_NT") ? atoi(knob("SS_KW_NT")) : 0;        // (tuning build: workgroup size of the walk)
+                const int nt2 = kw_nt == 512 || H > 64 ? 512 : 256, tiles2 = (nchunks + (nt2 - H) - 1) / (nt2 - H);
+                auto kern = nt2 == 256 ? (hps ? k_kw_fused32<256, true> : k_kw_fused32<256, false>) : (hps ? k_kw_fused32<512, true> : k_kw_fused32<512, false>);
+                hipLaunchKernelGGL(kern, dim3(tiles2, C), dim3(nt2), 0, stream, da, T, st, sc, kf, planef, nchunks, H, states, energy, k.c[1][3] * k.c[1][3]);
+            }
         }
     } else {
         hipLaunchKernelGGL(k_kw_state, dim3((nthreads + 255) / 256), dim3(256), 0, stream, da, T, C, st, sc, kd, nchunks, states);
@@ -4142,7 +4323,7 @@ int ss_scale_f32(const float* in, float* out, int64_t n, float gain, double* sum
 #ifdef SS_DEBUG_CLK
 int ss_debug_clk(unsigned long long* out) {
     HIPCHK(hipDeviceSynchronize());
-    HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg_clk), sizeof(unsigned long long) * 8 * 2 * 256));
+    HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg_clk), sizeof(unsigned long long) * 12 * 2 * 256));
     return SS_OK;
 }
 #endif

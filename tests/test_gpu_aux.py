@@ -422,7 +422,7 @@ def test_mix_keep_speakers_and_vector_path(gpu):
 
 
 def test_device_loudness_ebu_tech_3341_cases(gpu):
-    """the device path of row U (float64 K-weighting scan, block powers, gating on the GPU) on the published EBU Tech 3341 integrated-
+    """the device path of row U (float32 K-weighting walk, float64 block powers and gating on the GPU) on the published EBU Tech 3341 integrated-
     loudness cases 1-6: within +-0.1 LU of the expected reading and within 1e-5 dB of the NumPy oracle"""
     from sonicsim_amd import SonicSim_audio as A
     from util import ebu3341_case
@@ -431,6 +431,39 @@ def test_device_loudness_ebu_tech_3341_cases(gpu):
         got = A.integrated_loudness(torch.from_numpy(x).to(gpu), 48000)
         assert abs(got - want) <= 0.1, (case, got)
         assert abs(got - OL.integrated_loudness(x, 48000)) < 1e-5, case
+
+
+def test_float32_walk_within_1e6_of_the_float64_engines(gpu, monkeypatch):
+    """round 6: the K-weighting walk of the fused kernel runs in float32 (delta-form biquads, k_kw_fused32).  Bar: the gain it leads to
+    within 1e-6 relative of the float64 engine's (SS_KW_EXACT=1: the multi-launch float64 scan) and of the oracle's (SciPy float64 lfilter), here over
+    signals chosen to hurt float32 -- tones at 50 / 100 Hz, brown noise, a DC offset of 0.3, a stem at -50 LUFS -- at 16 / 48 / 44.1 / 8 kHz; the float64
+    engine itself stays within 1e-9 dB of the oracle."""
+    import scipy.signal as sg
+    from sonicsim_amd import SonicSim_audio as A
+    rng = np.random.default_rng(10)
+    worst = 0.0
+    for fs in (16000, 48000, 44100, 8000):
+        T = fs * 6 + 37
+        t = np.arange(T) / fs
+        env = np.repeat(rng.uniform(0, 1, size=T // 8000 + 1), 8000)[:T]
+        brown = sg.lfilter([1], [1, -0.995], rng.standard_normal(T))
+        for name, x in (("noise", rng.standard_normal(T) * 0.05 * env), ("noise+dc", rng.standard_normal(T) * 0.05 * env + 0.3),
+                        ("sine50", 0.3 * np.sin(2 * np.pi * 50 * t)), ("sine100+noise", 0.3 * np.sin(2 * np.pi * 100 * t) + 0.001 * rng.standard_normal(T)),
+                        ("sine997", 0.5 * np.sin(2 * np.pi * 997 * t)), ("brown", 0.2 * brown / np.abs(brown).max()),
+                        ("quiet", rng.standard_normal(T) * 3e-3 * env)):
+            a = np.stack([x, x[::-1] * 0.7], axis=1).astype(np.float32)
+            ref = OL.integrated_loudness(a, fs, mirror_dtype=False)
+            monkeypatch.setenv("SS_KW_EXACT", "0")
+            got = A.integrated_loudness(a, fs)
+            monkeypatch.setenv("SS_KW_EXACT", "1")
+            exact = A.integrated_loudness(a, fs)
+            assert abs(exact - ref) < 1e-9, (fs, name, exact, ref)
+            for other in (ref, exact):
+                dgain = abs(10 ** ((other - got) / 20) - 1)
+                worst = max(worst, dgain)
+                assert dgain < 1e-6, (fs, name, got, other)
+    monkeypatch.delenv("SS_KW_EXACT")
+    print(f"float32 walk: worst relative gain difference {worst:.2e}")
 
 
 def test_batched_bank_generator_same_values_as_bank_by_bank(gpu):

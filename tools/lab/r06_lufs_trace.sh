@@ -11,7 +11,7 @@ tot = 0
 for r in csv.DictReader(open(sys.argv[1])):
     n = r["Name"].split("(")[0].replace("void ", "")
     if n.startswith("k_"):
-        print("  %-28s calls %4s avg %.2f us" % (n[:28], r["Calls"], float(r["AverageNs"]) / 1e3)); tot += float(r["AverageNs"]) / 1e3
+        print("  %-28s calls %4s avg %.2f us (min %.2f, max %.2f)" % (n[:28], r["Calls"], float(r["AverageNs"]) / 1e3, float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3)); tot += float(r["AverageNs"]) / 1e3
 print("  sum of averages %.1f us" % tot)
 PY
 rm -rf $OUT/tr
