@@ -658,6 +658,7 @@ __device__ __forceinline__ void noise_pair(uint32_t a, float& g0, float& g1) {
 // so the parallelism is C * L / V threads: two taps per thread give a config-2 bank 3 000 waves for the 1 024 SIMDs; the position loop is
 // unrolled by two (two positions' hash / Box-Muller chains in flight per thread).
 // peak_bits (may be null): max |bank| over the whole bank -- row G's abs().max() for free; slots: 1 + gridDim.x words of workspace.
+constexpr int RIR_GEOM_LDS = 2048;     // (position, channel) pairs of geometry a workgroup keeps in LDS: P <= 1024 for the usual two channels per workgroup
 template <bool FAST32, int V>
 __device__ __forceinline__ void rir_synth_body(const RirDev& p, float* __restrict__ bank, unsigned int* __restrict__ peak_bits,
                                                unsigned int* __restrict__ slots, const unsigned bx, const unsigned gx) {
@@ -677,10 +678,47 @@ __device__ __forceinline__ void rir_synth_body(const RirDev& p, float* __restric
     const float* dg = p.dgain + c;
     const uint32_t k1 = p.seed * 0x9E3779B9u + 1u;
     const uint32_t h1c = fmix32(k1);
-    int d_next = dl[0];
-    auto step = [&](int q) {
-        const int d = d_next;                                        // this position's direct-path delay was requested an iteration ago
-        if (q + 1 < p.P) d_next = dl[(int64_t)(q + 1) * p.C];
+    // The geometry of the workgroup's channel(s) goes to LDS once (round 6): a global load inside the position loop shares `vmcnt` with the stores, and
+    // on this chip the counter retires in order -- waiting for the next position's delay meant waiting for the acknowledgement of every store issued
+    // before it (~0.8 us each time: 420 ns per position and wave, the "latency" a bank of 200 positions ran at: 84 us where its stores alone take 43).
+    __shared__ int32_t s_del[RIR_GEOM_LDS];
+    __shared__ float s_dg[RIR_GEOM_LDS];
+    const int64_t i_lo = (int64_t)bx * 256 * V, i_hi = (i_lo + 256 * V < CL ? i_lo + 256 * V : CL) - 1;
+    const int c_lo = (int)(i_lo / p.L), nspan = (int)(i_hi / p.L) - c_lo + 1;
+    const bool geom_lds = (int64_t)nspan * p.P <= RIR_GEOM_LDS;
+    if (geom_lds) {
+        for (int kk = threadIdx.x; kk < nspan * p.P; kk += 256) {
+            const int cc = kk / p.P, q = kk - cc * p.P;
+            s_del[kk] = p.delay[(int64_t)q * p.C + c_lo + cc];
+            s_dg[kk] = p.dgain[(int64_t)q * p.C + c_lo + cc];
+        }
+        __syncthreads();
+    }
+    const int32_t* sd = s_del + (c - c_lo) * p.P;
+    const float* sg = s_dg + (c - c_lo) * p.P;
+    // Waves whose taps all lie behind every direct-path delay of their channel(s) -- at config-2 shapes all but the first wave or two of each channel --
+    // need neither the delay gate nor the impulse test: their loop has no LDS read, no compare, no select (a fifth of its instructions; same values).
+    bool ungated = false;
+    if (geom_lds) {
+        __shared__ int s_dmax[4];
+        int dm = INT32_MIN;
+        for (int kk = threadIdx.x; kk < nspan * p.P; kk += 256) dm = s_del[kk] > dm ? s_del[kk] : dm;
+        for (int o = 32; o > 0; o >>= 1) { const int v = __shfl_xor(dm, o); dm = v > dm ? v : dm; }
+        if ((threadIdx.x & 63) == 0) s_dmax[threadIdx.x >> 6] = dm;
+        __syncthreads();
+        dm = max(max(s_dmax[0], s_dmax[1]), max(s_dmax[2], s_dmax[3]));
+        ungated = __all(t0 > dm) != 0;
+    }
+    int d_next = geom_lds ? sd[0] : dl[0];
+    uint32_t pr32 = (uint32_t)(ctr >> 1);                            // FAST32, V >= 2: the pair counter is 32 bits and advances by C L / 2 per position
+    const uint32_t pr_step = (uint32_t)(CL >> 1);
+    auto step = [&](int q, auto lds_tag, auto gate_tag) {            // (two loop bodies per address space: one pointer of either would be a FLAT load -- vmcnt again)
+        constexpr bool GL = decltype(lds_tag)::value, GATE = decltype(gate_tag)::value;
+        int d = 0;
+        if (GATE) {
+            d = d_next;                                              // this position's direct-path delay was requested an iteration ago
+            if (q + 1 < p.P) d_next = GL ? sd[q + 1] : dl[(int64_t)(q + 1) * p.C];
+        }
         float g[V];
         if (V == 1) {
             const uint64_t pr = ctr >> 1;
@@ -691,7 +729,7 @@ __device__ __forceinline__ void rir_synth_body(const RirDev& p, float* __restric
 #pragma unroll
             for (int v = 0; v < V; v += 2) {
                 const uint64_t pr = (ctr + (uint64_t)v) >> 1;
-                noise_pair(FAST32 ? fmix32((uint32_t)pr ^ h1c) : fmix32((uint32_t)pr ^ fmix32((uint32_t)(pr >> 32) ^ k1)), g[v], g[v + (V > 1 ? 1 : 0)]);
+                noise_pair(FAST32 ? fmix32((pr32 + (uint32_t)(v >> 1)) ^ h1c) : fmix32((uint32_t)pr ^ fmix32((uint32_t)(pr >> 32) ^ k1)), g[v], g[v + (V > 1 ? 1 : 0)]);
             }
         }
         float val[V];
@@ -699,10 +737,10 @@ __device__ __forceinline__ void rir_synth_body(const RirDev& p, float* __restric
         for (int v = 0; v < V; ++v) {
             n[v] = (q == 0) ? g[v] : (p.rho * n[v] + p.srho * g[v]);
             const int t = t0 + v;
-            val[v] = (t > d) ? te[v] * n[v] : 0.0f;
+            val[v] = (!GATE || t > d) ? te[v] * n[v] : 0.0f;
         }
-        if ((unsigned)(d - t0) < (unsigned)V) {                      // the direct-path impulse falls on one of this thread's taps: one thread
-            const float dgain = dg[(int64_t)q * p.C];                // per (position, channel) -- a rarely taken branch, not selects per tap
+        if (GATE && (unsigned)(d - t0) < (unsigned)V) {              // the direct-path impulse falls on one of this thread's taps: one thread
+            const float dgain = GL ? sg[q] : dg[(int64_t)q * p.C];   // per (position, channel) -- a rarely taken branch, not selects per tap
 #pragma unroll
             for (int v = 0; v < V; ++v)
                 if (t0 + v == d) val[v] += dgain;
@@ -717,13 +755,17 @@ __device__ __forceinline__ void rir_synth_body(const RirDev& p, float* __restric
                 for (int v = 0; v < V; ++v) out[v] = val[v];
         }
         out += CL;
-        ctr += (uint64_t)CL;
+        if (FAST32 && V >= 2) pr32 += pr_step;
+        else ctr += (uint64_t)CL;
     };
-    {
+    auto run = [&](auto lds_tag, auto gate_tag) {
         int q = 0;
-        for (; q + 1 < p.P; q += 2) { step(q); step(q + 1); }
-        for (; q < p.P; ++q) step(q);
-    }
+        for (; q + 1 < p.P; q += 2) { step(q, lds_tag, gate_tag); step(q + 1, lds_tag, gate_tag); }
+        for (; q < p.P; ++q) step(q, lds_tag, gate_tag);
+    };
+    if (ungated) run(std::true_type{}, std::false_type{});
+    else if (geom_lds) run(std::true_type{}, std::true_type{});
+    else run(std::false_type{}, std::true_type{});
     if (peak_bits) {
         // max |bank| without an initialised result word (a hipMemsetAsync ahead of the kernel is 4 us + a 6 us boundary, profiles/r03g):
         // every workgroup publishes its maximum in its own slot (write-through store), draws an arrival ticket, and the LAST arriver
@@ -3478,7 +3520,7 @@ int ss_rir_bank_synth_batch_f32(int32_t n, const SsRirParams* prm, float* const*
     // the widest form every bank admits (the same choice rir_synth makes for one bank: values do not depend on it)
     bool all4 = true;
     for (int b = 0; b < n; ++b) all4 = all4 && prm[b].L % 4 == 0;
-    const bool vec4 = all4 && CL / 4 / 64 >= (int64_t)c->num_cu * 32;
+    const bool vec4 = all4 && CL / 4 / 64 >= (int64_t)c->num_cu * 32;        // (four taps per thread in a scene's five-bank launch: 192-193 us against 187-195, profiles/r06ao)
     const unsigned gx = (unsigned)((CL / (vec4 ? 4 : 2) + 255) / 256);
     const size_t per = (size_t)gx + 1, needw = sizeof(unsigned int) * per * 8;
     if (c->ws_cap[WS_K1] < needw) {

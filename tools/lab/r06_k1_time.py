@@ -3,13 +3,16 @@
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
+from sonicsim_amd import _lib as _sslib
+if os.environ.get("BENCH_LIB"):
+    _sslib.use_library(os.environ["BENCH_LIB"])
 from sonicsim_amd import ops, synth
 ops.init(0); dev = torch.device("cuda:0")
 sc = synth.make_scene("cfg2", scene=0)
 d, g = torch.from_numpy(sc.delay).to(dev), torch.from_numpy(sc.dgain).to(dev)
 out = torch.empty((sc.P, sc.C, sc.L), device=dev); pk = torch.empty(1, device=dev)
-def ev(fn, n=30):
-    for _ in range(5): fn()
+def ev(fn, n=300):
+    for _ in range(60): fn()
     torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
