@@ -1049,9 +1049,11 @@ def run_scenes(args, rank, local_rank, world, dev):
             xs_ = [q[0] for q in sp_.speakers] + [q[0] for q in sp_.statics]
             ops.convolve_scene(xs_, banks, [q[3] for q in sp_.speakers] + [None, None], peaks=list(peaks) + [None, None], outs=[rend.stack[i] for i in range(5)])
             ev[2].record()
-            nstack, _res, sq_ = A.get_lufs_norm_audio_batch(rend.stack, sp_.fs, pipeline.LUFS_TARGETS, allow_many_channels=True, sync=False, want_sumsq=True)
+            nstack, _res, sq_ = A.get_lufs_norm_audio_batch(rend.stack, sp_.fs, pipeline.LUFS_TARGETS, allow_many_channels=True, sync=False, want_sumsq=True,
+                                                            cross_speakers=2)                  # (as pipeline._normalise_and_mix: the one-pass mix of round 6)
             ev[3].record()
-            mixing.mix_sources(nstack[:2], nstack[3][None], np.asarray([1.5], np.float32), 15.0, keep_speakers=True, presums=(sq_[:2], sq_[3:4]))
+            mixing.mix_sources(nstack[:2], nstack[3][None], np.asarray([1.5], np.float32), 15.0, keep_speakers=True,
+                               presums=(sq_[:2], sq_[3:4]) + ((sq_[5:6],) if sq_.numel() == 6 else ()))
             ev[4].record()
             torch.cuda.synchronize()
             if rep >= 2:
@@ -1062,7 +1064,7 @@ def run_scenes(args, rank, local_rank, world, dev):
                   for k_, v_ in acc.items()}
         stages["note"] = ("stages launched one after the other on one stream with torch events between them (no provider prefetch), mean of 8 scenes; bytes: K1 = the "
                           "banks it writes, render = SURVEY 8d's render bytes + the zero fill of the five stems, loudness = read + write of five stems, mix = read 3 + "
-                          "write 1 (round 5: the stems' energies ride on the loudness scale pass, ss_mix_presum_f32); the sum exceeds ms_per_step because the timed region overlaps the next scene's K1 with loudness / mix")
+                          "write 1 (round 6: energies and the speakers cross sum ride on the loudness scale pass, the mix is one launch: ss_mix_onepass_f32); the sum exceeds ms_per_step because the timed region overlaps the next scene's K1 with loudness / mix")
     except Exception as e:                                   # noqa: BLE001 -- informational
         stages = {"error": repr(e)}
     roof["scene"]["stages"] = stages

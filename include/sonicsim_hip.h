@@ -345,6 +345,22 @@ int ss_lufs_norm_batch_sq_f32(const float* audio, float* out, int64_t T, int32_t
 int ss_mix_presum_f32(float* speakers, int32_t S, const float* noise, int64_t n, const float* sirs, float snr, float* mix,
                       const double* sumsq_speakers, const double* sumsq_noise, float* gains_dev, uint32_t flags, void* stream);
 
+/* ---- round 6: the mix in ONE pass.
+ * ss_lufs_norm_batch_sqx_f32 = ss_lufs_norm_batch_sq_f32 whose first nspk stems (2 <= nspk <= 4) are the speakers of the mix that follows: the pass that
+ * writes the normalised stems also leaves their cross sums sum(out[i] * out[j]) behind the S energies, sums[S + j (j - 1) / 2 + i] for i < j < nspk
+ * (the workgroups of speaker j read the inputs of the speakers before it once more: +1 stem of reads for two speakers).  Stems 16-byte aligned, C * T % 4 == 0.
+ * ss_mix_onepass_f32 = ss_mix_presum_f32 with those sums (sumsq_speakers[S] and cross_speakers[S (S - 1) / 2] in the order above, device doubles): the energy of
+ * the speech sum s_0 + sum g_s s_s (movingdatamodule.py:113-118) follows from them in float64, so interferer gains, noise gain and the mix itself are ONE
+ * launch reading every stem once -- 123 MB instead of 184 MB for a 2-speaker 8 x 960 000 mix.  Per sample the same float32 operations; the speech energy
+ * is the exact quadratic form instead of the sum over the float32-rounded speech sum (1e-10 relative apart), so the noise gain may differ in a last bit. */
+int ss_lufs_norm_batch_sqx_f32(const float* audio, float* out, int64_t T, int32_t C, int32_t S, int32_t nspk,
+                               const double* coef, const int64_t* lo, const int64_t* hi, int32_t nblocks,
+                               double block_norm, const double* weights, const double* targets,
+                               double* result, double* sums, uint32_t flags, void* stream);
+int ss_mix_onepass_f32(float* speakers, int32_t S, const float* noise, int64_t n, const float* sirs, float snr, float* mix,
+                       const double* sumsq_speakers, const double* cross_speakers, const double* sumsq_noise, float* gains_dev, uint32_t flags,
+                       void* stream);
+
 /* ---- measurement hooks (bench.py): HIP-event timing of the dominant kernels on their own stream.
  * kind 0 = overlap-save render kernel (one parity pass = one launch), 1 = input-spectra kernel,
  * 2 = direct-form kernel.  ss_prof_enable(0) = off, 1 = every launch, N > 1 = every N-th launch of each

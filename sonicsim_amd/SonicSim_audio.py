@@ -182,7 +182,8 @@ def lufs_norm(data, sr, norm=-6, allow_many_channels: bool = False, channel_firs
     return norm_data, gain
 
 
-def get_lufs_norm_audio_batch(stems, sr=16000, lufs=(-6,), allow_many_channels: bool = False, sync: bool = True, want_sumsq: bool = False):
+def get_lufs_norm_audio_batch(stems, sr=16000, lufs=(-6,), allow_many_channels: bool = False, sync: bool = True, want_sumsq: bool = False,
+                              cross_speakers: int = 0):
     """Extension: ``get_lufs_norm_audio`` for a stack of stems (S, C, T) in ONE device call.  The class loudness of stem i
     is drawn from the global NumPy RNG in stem order, exactly as S successive reference calls (:83-86) would draw them.
     Returns (normalised stack (S, C, T), [gain_0, ...]).  sync=False (device stacks): the call only enqueues work and returns the raw
@@ -196,7 +197,9 @@ def get_lufs_norm_audio_batch(stems, sr=16000, lufs=(-6,), allow_many_channels: 
     block_size = 0.4 if T / sr >= 0.4 else T / sr
     _, lo, hi, weights, _ = _meter_args(stems[0], sr, block_size, allow_many_channels, True)
     if not sync and want_sumsq:          # (out, records, sum(out[s] ** 2) per stem on the device: what the mix of these stems needs, ops.mix(presums=))
-        return ops.lufs_norm(stems, _kw_coef(float(sr)), lo, hi, block_size * sr, weights, targets, layout_tc=False, result_device=True, want_sumsq=True)
+        cs = cross_speakers if (cross_speakers and 2 <= cross_speakers <= min(S, 4) and (C * T) % 4 == 0 and stems.data_ptr() % 16 == 0) else 0
+        return ops.lufs_norm(stems, _kw_coef(float(sr)), lo, hi, block_size * sr, weights, targets, layout_tc=False, result_device=True, want_sumsq=True,
+                             cross_speakers=cs)     # (cs > 1: the speakers' cross sums follow the S energies: ops.mix then needs ONE pass)
     if not sync:
         out, res = ops.lufs_norm(stems, _kw_coef(float(sr)), lo, hi, block_size * sr, weights, targets, layout_tc=False, result_device=True)
         return out, res                 # (S, 4) float64 on the device: {loudness, linear gain, sum(out), sum(in)}; see lufs_gains_from_result

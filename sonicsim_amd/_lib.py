@@ -115,6 +115,11 @@ _SIGS = {
                                                  ctypes.c_uint32, ctypes.c_void_p]),
     "ss_mix_presum_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int64, c_f32p, ctypes.c_float, ctypes.c_void_p,
                                          ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p]),
+    "ss_lufs_norm_batch_sqx_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, c_f64p,
+                                                  c_i64p, c_i64p, ctypes.c_int32, ctypes.c_double, c_f64p, c_f64p, ctypes.c_void_p, ctypes.c_void_p,
+                                                  ctypes.c_uint32, ctypes.c_void_p]),
+    "ss_mix_onepass_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int64, c_f32p, ctypes.c_float, ctypes.c_void_p,
+                                          ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p]),
     "ss_gather_create": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p]),
     "ss_gather_attach": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64]),
     "ss_gather_slot": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(ctypes.c_void_p)]),

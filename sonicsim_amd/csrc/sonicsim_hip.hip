@@ -940,8 +940,14 @@ __device__ __forceinline__ double wave_final_sum(const double* __restrict__ part
     return s;
 }
 __global__ __launch_bounds__(64) void k_lufs_result(const double* __restrict__ res, const double* __restrict__ part, int nb, double* __restrict__ out,
-                                                    const double* __restrict__ part_sq = nullptr, double* __restrict__ sumsq = nullptr) {
+                                                    const double* __restrict__ part_sq = nullptr, double* __restrict__ sumsq = nullptr,
+                                                    int S = 0, const double* __restrict__ part_x = nullptr) {
     const int g = blockIdx.x;
+    if (part_x && g >= S) {          // blocks S ..: the cross sums of the speaker pairs, behind the S energies
+        const double v = wave_final_sum(part_x + (int64_t)(g - S) * nb, nb, (int)threadIdx.x);
+        if (threadIdx.x == 0) sumsq[g] = v;
+        return;
+    }
     double s0 = 0.0, s1 = 0.0;
     if (part_sq) {                   // sum(out^2) of stem g for the mix that follows (ss_mix_presum_f32)
         const double v = wave_final_sum(part_sq + (int64_t)g * nb, nb, (int)threadIdx.x);
@@ -972,12 +978,72 @@ __global__ __launch_bounds__(64) void k_final_sum(const double* __restrict__ par
 // gain_dev != nullptr: the gain is the float64 the gating kernel left on the device (rounded to float32 like the host path).
 // blockIdx.y = group (stem): its n elements start at group * n, its gain is gain_dev[4 * group], its partial sums go to
 // partial[(2 * group + {0,1}) * gridDim.x + blockIdx.x].
+// nspk > 1 (round 6, ss_lufs_norm_batch_sqx_f32): the first nspk stems are the speakers of the mix that follows; the workgroups of speaker j < nspk also read
+// the inputs of the speakers i < j at the same indices, form out_i = gain_i * in_i as that stem's own workgroups do, and leave the partial sums of
+// out_i * out_j in partial_x[pair][grid] (pairs in the order (0,1), (0,2), (1,2), (0,3) ...): with them the energy of the speech sum is known without a pass
+// over it and the mix is ONE pass (ss_mix_onepass_f32).
+constexpr int SCALE_XMAX = 3;        // speakers i < j a workgroup reads beside its own stem: nspk <= 4
 __global__ __launch_bounds__(256) void k_scale_sums(const float* __restrict__ in, float* __restrict__ out, int64_t n, float gain,
                                                     const double* __restrict__ gain_dev, double* __restrict__ partial /*[groups][2][grid]*/,
-                                                    double* __restrict__ partial_sq = nullptr /*[groups][grid]: sum(out^2), or null*/) {
+                                                    double* __restrict__ partial_sq = nullptr /*[groups][grid]: sum(out^2), or null*/,
+                                                    int nspk = 0, double* __restrict__ partial_x = nullptr /*[pairs][grid]*/) {
     __shared__ double sw[3][4];
     double sq = 0.0;                 // round 5: the energy the mix needs of every normalised stem rides on the pass that writes it (ss_mix_presum_f32)
     if (gain_dev) gain = (float)gain_dev[4 * blockIdx.y];
+    if (partial_x && (int)blockIdx.y >= 1 && (int)blockIdx.y < nspk && (((uintptr_t)in | (uintptr_t)out) & 15) == 0 && (n & 3) == 0) {
+        // speaker j >= 1: the same pass with the cross sums (aligned stems of whole float4s: the mix's own requirement)
+        const int j = (int)blockIdx.y;
+        float gi[SCALE_XMAX];
+        const float4* oth[SCALE_XMAX];
+        double cx[SCALE_XMAX];
+#pragma unroll
+        for (int i = 0; i < SCALE_XMAX; ++i) {
+            gi[i] = i < j ? (float)gain_dev[4 * i] : 0.0f;
+            oth[i] = (const float4*)(in + (int64_t)(i < j ? i : 0) * n);
+            cx[i] = 0.0;
+        }
+        const float4* in4 = (const float4*)(in + (int64_t)j * n);
+        float4* out4 = (float4*)(out + (int64_t)j * n);
+        double so = 0.0, si = 0.0;
+        const int64_t stride = (int64_t)gridDim.x * 256, n4 = n >> 2;
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+            const float4 v = in4[i];
+            float4 o;
+            o.x = gain * v.x; o.y = gain * v.y; o.z = gain * v.z; o.w = gain * v.w;
+            out4[i] = o;
+            so += ((double)o.x + (double)o.y) + ((double)o.z + (double)o.w);
+            si += ((double)v.x + (double)v.y) + ((double)v.z + (double)v.w);
+            sq += ((double)o.x * (double)o.x + (double)o.y * (double)o.y) + ((double)o.z * (double)o.z + (double)o.w * (double)o.w);
+#pragma unroll
+            for (int k = 0; k < SCALE_XMAX; ++k)
+                if (k < j) {
+                    const float4 u = oth[k][i];
+                    const float ux = gi[k] * u.x, uy = gi[k] * u.y, uz = gi[k] * u.z, uw = gi[k] * u.w;
+                    cx[k] += ((double)ux * (double)o.x + (double)uy * (double)o.y) + ((double)uz * (double)o.z + (double)uw * (double)o.w);
+                }
+        }
+        __shared__ double swx[SCALE_XMAX][4];
+        for (int o = 32; o > 0; o >>= 1) {
+            so += __shfl_xor(so, o); si += __shfl_xor(si, o); sq += __shfl_xor(sq, o);
+#pragma unroll
+            for (int k = 0; k < SCALE_XMAX; ++k) cx[k] += __shfl_xor(cx[k], o);
+        }
+        if ((threadIdx.x & 63) == 0) {
+            sw[0][threadIdx.x >> 6] = so; sw[1][threadIdx.x >> 6] = si; sw[2][threadIdx.x >> 6] = sq;
+#pragma unroll
+            for (int k = 0; k < SCALE_XMAX; ++k) swx[k][threadIdx.x >> 6] = cx[k];
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double* pj = partial + (int64_t)2 * j * gridDim.x;
+            pj[blockIdx.x] = (sw[0][0] + sw[0][1]) + (sw[0][2] + sw[0][3]);
+            pj[gridDim.x + blockIdx.x] = (sw[1][0] + sw[1][1]) + (sw[1][2] + sw[1][3]);
+            if (partial_sq) partial_sq[(int64_t)j * gridDim.x + blockIdx.x] = (sw[2][0] + sw[2][1]) + (sw[2][2] + sw[2][3]);
+            for (int k = 0; k < j && k < SCALE_XMAX; ++k)
+                partial_x[((int64_t)(j * (j - 1) / 2 + k)) * gridDim.x + blockIdx.x] = (swx[k][0] + swx[k][1]) + (swx[k][2] + swx[k][3]);
+        }
+        return;
+    }
     in += (int64_t)blockIdx.y * n;
     out += (int64_t)blockIdx.y * n;
     partial += (int64_t)2 * blockIdx.y * gridDim.x;
@@ -1194,6 +1260,60 @@ __global__ __launch_bounds__(256) void k_mix_pre_final4(const float* __restrict_
         float4 m = mix4[i];
         m.x = m.x + (0.0f + nz.x) * gn; m.y = m.y + (0.0f + nz.y) * gn; m.z = m.z + (0.0f + nz.z) * gn; m.w = m.w + (0.0f + nz.w) * gn;
         mix4[i] = m;
+    }
+}
+
+// round 6: the mix in ONE pass (ss_mix_onepass_f32).  With the speakers' energies E_ss and cross sums C_st known (k_scale_sums) the energy of the speech
+// sum sp = s_0 + sum g_s s_s is E = sum_s g_s^2 E_ss + 2 sum_{s<t} g_s g_t C_st (g_0 = 1) -- float64, from the float64 sums; it differs from the sum over
+// the float32-rounded sp by ~1e-10 relative (the roundings of sp are uncorrelated), so the noise gain is the two-pass form's up to a rare last bit.
+// Per sample the same float32 operations as k_mix_pre_scale_sum4 + k_mix_pre_final4; 123 MB instead of 184 MB for a 2-speaker 8 x 960 000 mix.
+__global__ __launch_bounds__(256) void k_mix_onepass4(float* __restrict__ spk, int S, const float* __restrict__ noise, int64_t n4,
+                                                      const double* __restrict__ sums /*[S]*/, const double* __restrict__ cross /*[S (S - 1) / 2]*/,
+                                                      const double* __restrict__ sumsq_noise,
+                                                      double n_elems, const SirTab sir_tab, float snr, float* __restrict__ mix,
+                                                      float* __restrict__ g_out /*[S + 1]*/, int write_back) {
+    __shared__ float gs_[64];
+    __shared__ float gn_;
+    if ((int)threadIdx.x < S) {
+        float g = 1.0f;
+        if (threadIdx.x >= 1) {
+            const double e0 = rms_db_from_sumsq(sums[0], n_elems), ei = rms_db_from_sumsq(sums[threadIdx.x], n_elems);
+            double gain = e0 - ei - (double)sir_tab.v[threadIdx.x - 1];
+            gain = gain < 40.0 ? gain : 40.0;
+            g = (float)pow(10.0, gain / 20.0);
+        }
+        gs_[threadIdx.x] = g;
+        if (blockIdx.x == 0) g_out[threadIdx.x] = g;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double es = 0.0;
+        for (int a = 0; a < S; ++a) es += (double)gs_[a] * (double)gs_[a] * sums[a];
+        for (int b = 1; b < S; ++b)
+            for (int a = 0; a < b; ++a) es += 2.0 * (double)gs_[a] * (double)gs_[b] * cross[b * (b - 1) / 2 + a];
+        double gain = rms_db_from_sumsq(es, n_elems) - rms_db_from_sumsq(sumsq_noise[0], n_elems) - (double)snr;
+        gain = gain < 40.0 ? gain : 40.0;
+        gn_ = (float)pow(10.0, gain / 20.0);
+        if (blockIdx.x == 0) g_out[S] = gn_;
+    }
+    __syncthreads();
+    const float gn = gn_;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    float4* spk4 = reinterpret_cast<float4*>(spk);
+    const float4* noi4 = reinterpret_cast<const float4*>(noise);
+    float4* mix4 = reinterpret_cast<float4*>(mix);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+        float4 sp = spk4[i];
+        const float4 nz = noi4[i];
+        for (int s = 1; s < S; ++s) {
+            const float gs = gs_[s];
+            float4 v = spk4[(int64_t)s * n4 + i];
+            v.x *= gs; v.y *= gs; v.z *= gs; v.w *= gs;
+            if (write_back) spk4[(int64_t)s * n4 + i] = v;
+            sp.x += v.x; sp.y += v.y; sp.z += v.z; sp.w += v.w;
+        }
+        sp.x = sp.x + (0.0f + nz.x) * gn; sp.y = sp.y + (0.0f + nz.y) * gn; sp.z = sp.z + (0.0f + nz.z) * gn; sp.w = sp.w + (0.0f + nz.w) * gn;
+        mix4[i] = sp;
     }
 }
 
@@ -3731,6 +3851,31 @@ int ss_mix_presum_f32(float* speakers, int32_t S, const float* noise, int64_t n,
     return SS_OK;
 }
 
+int ss_mix_onepass_f32(float* speakers, int32_t S, const float* noise, int64_t n, const float* sirs, float snr, float* mix,
+                       const double* sumsq_speakers, const double* cross_speakers, const double* sumsq_noise, float* gains_dev, uint32_t flags, void* stream_) {
+    if (S < 1 || S > 64 || n <= 0 || !speakers || !noise || !mix || !sumsq_speakers || !sumsq_noise || (S > 1 && (!sirs || !cross_speakers)))
+        return fail(SS_EINVAL, "bad argument");
+    if (!(flags & SS_FLAG_DEVICE_PTR)) return fail(SS_EINVAL, "device pointers only (SS_FLAG_DEVICE_PTR): the stem energies are device-side by-products");
+    if (n % 4 != 0 || (((uintptr_t)speakers | (uintptr_t)noise | (uintptr_t)mix) & 15) != 0)
+        return fail(SS_EINVAL, "ss_mix_onepass_f32 needs 16-byte aligned stems of a multiple of four samples (use ss_mix_f32)");
+    Ctx* c;
+    int rc = get_ctx(&c);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(c->mu);
+    hipStream_t stream = (hipStream_t)stream_;
+    if ((rc = stream_enter(c, stream))) return rc;
+    const int write_back = (flags & SS_FLAG_KEEP_SPEAKERS) ? 0 : 1;
+    if ((rc = ws_ensure(c, WS_SCR2, sizeof(float) * ((size_t)S + 1) + 16))) return rc;
+    float* d_g = gains_dev ? gains_dev : (float*)c->ws[WS_SCR2];
+    SirTab sir_tab;
+    memset(&sir_tab, 0, sizeof(sir_tab));
+    for (int i = 0; i + 1 < S; ++i) sir_tab.v[i] = sirs[i];
+    hipLaunchKernelGGL(k_mix_onepass4, dim3(grid_for(n / 4)), dim3(256), 0, stream, speakers, S, noise, n / 4, sumsq_speakers, cross_speakers, sumsq_noise,
+                       (double)n, sir_tab, snr, mix, d_g, write_back);
+    HIPCHK(hipGetLastError());
+    return SS_OK;
+}
+
 // K-weighting coefficients -> KwCoef (normalised biquads + the powers of the chunk transition matrix the scan needs)
 static int kw_setup(const double* coef, KwCoef& k) {
     // the tables depend on the 12 coefficients only (one set per sample rate): reuse the last set's tables
@@ -3935,7 +4080,10 @@ int ss_kweighted_block_power_f32(const float* audio, int64_t T, int32_t C, const
 
 static int lufs_norm_batch(const float* audio, float* out, int64_t T, int32_t C, int32_t S, const double* coef, const int64_t* lo,
                            const int64_t* hi, int32_t nblocks, double block_norm, const double* weights, const double* targets,
-                           double* result, uint32_t flags, void* stream_, double* sumsq_dev /* device [S]: sum(out^2) per stem, or null */) {
+                           double* result, uint32_t flags, void* stream_, double* sumsq_dev /* device [S]: sum(out^2) per stem, or null */,
+                           int nspk = 0 /* > 1: sumsq_dev has S + nspk (nspk - 1) / 2 entries, the cross sums of the first nspk stems behind the energies */) {
+    if (nspk > 1 && (!sumsq_dev || nspk > S || nspk > SCALE_XMAX + 1 || ((int64_t)C * T) % 4 != 0 || (((uintptr_t)audio | (uintptr_t)out) & 15) != 0))
+        return fail(SS_EINVAL, "cross sums: 2 <= speakers <= %d of the stems, 16-byte aligned stems of a multiple of four samples", SCALE_XMAX + 1);
     if (sumsq_dev && (flags & (SS_FLAG_DEVICE_PTR | SS_FLAG_RESULT_DEVICE)) != (SS_FLAG_DEVICE_PTR | SS_FLAG_RESULT_DEVICE))
         return fail(SS_EINVAL, "the stem energies are a device-side by-product: SS_FLAG_DEVICE_PTR | SS_FLAG_RESULT_DEVICE");
     if (!audio || !out || T <= 0 || C < 1 || S < 1 || S > 16 || (int64_t)C * S > 64 || !coef || nblocks < 0 || (nblocks && (!lo || !hi)) ||
@@ -3992,15 +4140,20 @@ static int lufs_norm_batch(const float* audio, float* out, int64_t T, int32_t C,
                        (const double*)c->ws[WS_GW], gt, zdev + (size_t)CC * nblocks, use_lds, res);
     double* part = res + 4 * (size_t)S;
     double* part_sq = nullptr;
+    double* part_x = nullptr;
+    const int npairs = nspk > 1 ? nspk * (nspk - 1) / 2 : 0;
     if (sumsq_dev) {
-        if ((rc = ws_ensure(c, WS_SQ, sizeof(double) * (size_t)S * nb))) return rc;
+        if ((rc = ws_ensure(c, WS_SQ, sizeof(double) * ((size_t)S + npairs) * nb))) return rc;
         part_sq = (double*)c->ws[WS_SQ];
+        if (npairs) part_x = part_sq + (size_t)S * nb;
     }
-    hipLaunchKernelGGL(k_scale_sums, dim3(nb, S), dim3(256), 0, stream, (const float*)da, dout, ng, 0.f, (const double*)(res + 1), part, part_sq);
+    hipLaunchKernelGGL(k_scale_sums, dim3(nb, S), dim3(256), 0, stream, (const float*)da, dout, ng, 0.f, (const double*)(res + 1), part, part_sq,
+                       nspk, part_x);
     HIPCHK(hipGetLastError());
     if (flags & SS_FLAG_RESULT_DEVICE) {      // no host synchronisation: the four numbers per stem land in the caller's device array
         if (!dev) return fail(SS_EINVAL, "SS_FLAG_RESULT_DEVICE needs SS_FLAG_DEVICE_PTR");
-        hipLaunchKernelGGL(k_lufs_result, dim3(S), dim3(64), 0, stream, (const double*)res, (const double*)part, nb, result, (const double*)part_sq, sumsq_dev);
+        hipLaunchKernelGGL(k_lufs_result, dim3(S + npairs), dim3(64), 0, stream, (const double*)res, (const double*)part, nb, result, (const double*)part_sq,
+                           sumsq_dev, (int)S, (const double*)part_x);
         HIPCHK(hipGetLastError());
         return SS_OK;
     }
@@ -4037,6 +4190,14 @@ int ss_lufs_norm_batch_sq_f32(const float* audio, float* out, int64_t T, int32_t
                               double* result, double* sumsq, uint32_t flags, void* stream_) {
     if (!sumsq) return fail(SS_EINVAL, "sumsq is NULL");
     return lufs_norm_batch(audio, out, T, C, S, coef, lo, hi, nblocks, block_norm, weights, targets, result, flags, stream_, sumsq);
+}
+
+int ss_lufs_norm_batch_sqx_f32(const float* audio, float* out, int64_t T, int32_t C, int32_t S, int32_t nspk, const double* coef, const int64_t* lo,
+                               const int64_t* hi, int32_t nblocks, double block_norm, const double* weights, const double* targets,
+                               double* result, double* sums, uint32_t flags, void* stream_) {
+    if (!sums) return fail(SS_EINVAL, "sums is NULL");
+    if (nspk < 2) return fail(SS_EINVAL, "nspk < 2: use ss_lufs_norm_batch_sq_f32");
+    return lufs_norm_batch(audio, out, T, C, S, coef, lo, hi, nblocks, block_norm, weights, targets, result, flags, stream_, sums, nspk);
 }
 
 int ss_lufs_norm_f32(const float* audio, float* out, int64_t T, int32_t C, const double* coef, const int64_t* lo, const int64_t* hi,

@@ -992,7 +992,8 @@ def mix(speaker_wav, noise_wav, sirs, snr, want_gains=True, out=None, keep_speak
     back (a scene generator keeps its normalised stems without cloning them first); the returned speaker tensor is then the input.
     presums=(speaker_sumsq (S,), noise_sumsq (1,)) (device form, one noise stem, want_gains=False): float64 device tensors with sum(x ** 2) of the
     stems -- by-products of ``lufs_norm(..., want_sumsq=True)`` -- so the mix does not measure them again (``ss_mix_presum_f32``: two launches
-    instead of five); stems that are not 16-byte aligned / a multiple of four samples take the ordinary path."""
+    instead of five); stems that are not 16-byte aligned / a multiple of four samples take the ordinary path.  A third entry -- the speakers' cross sums
+    (S (S - 1) / 2,), the tail of ``lufs_norm(..., cross_speakers=S)``'s sums -- makes the mix ONE pass (``ss_mix_onepass_f32``)."""
     lib = _lib.load()
     sirs = np.ascontiguousarray(np.asarray(sirs, dtype=np.float32).reshape(-1))
     if _is_dev(speaker_wav):
@@ -1011,10 +1012,17 @@ def mix(speaker_wav, noise_wav, sirs, snr, want_gains=True, out=None, keep_speak
         _set_device(spk)
         if (presums is not None and not want_gains and N == 1 and n % 4 == 0 and spk.data_ptr() % 16 == 0 and noi.data_ptr() % 16 == 0
                 and out.data_ptr() % 16 == 0):
-            ps, pn = presums
+            ps, pn = presums[0], presums[1]
+            px = presums[2] if len(presums) > 2 else None
             if not (_is_dev(ps) and _is_dev(pn) and ps.dtype == torch.float64 and pn.dtype == torch.float64 and ps.numel() == S and pn.numel() == 1
                     and ps.is_contiguous()):
-                raise ValueError("presums = (float64 device tensor (S,), float64 device tensor (1,))")
+                raise ValueError("presums = (float64 device tensor (S,), float64 device tensor (1,)[, float64 device tensor (S (S - 1) / 2,)])")
+            if px is not None and S > 1:
+                if not (_is_dev(px) and px.dtype == torch.float64 and px.numel() == S * (S - 1) // 2 and px.is_contiguous()):
+                    raise ValueError("presums[2] = the speakers' cross sums: float64 device tensor (S (S - 1) / 2,)")
+                _lib.check(lib.ss_mix_onepass_f32(_ptr(spk), S, _ptr(noi), n, sirs.ctypes.data_as(_lib.c_f32p), float(snr), _ptr(out), _ptr(ps), _ptr(px),
+                                                  _ptr(pn), None, _lib.FLAG_DEVICE_PTR | (_lib.FLAG_KEEP_SPEAKERS if keep_speakers else 0), _stream_ptr(spk)))
+                return out, spk, None
             _lib.check(lib.ss_mix_presum_f32(_ptr(spk), S, _ptr(noi), n, sirs.ctypes.data_as(_lib.c_f32p), float(snr), _ptr(out), _ptr(ps), _ptr(pn), None,
                                              _lib.FLAG_DEVICE_PTR | (_lib.FLAG_KEEP_SPEAKERS if keep_speakers else 0), _stream_ptr(spk)))
             return out, spk, None
@@ -1067,14 +1075,16 @@ def kweighted_block_power(audio, coef, lo, hi, norm, layout_tc=True):
 
 
 @_restores_device
-def lufs_norm(audio, coef, lo, hi, block_norm, weights, target_lufs, layout_tc=True, result_device=False, want_sumsq=False):
+def lufs_norm(audio, coef, lo, hi, block_norm, weights, target_lufs, layout_tc=True, result_device=False, want_sumsq=False, cross_speakers=0):
     """Row U in one call (SonicSim_audio.py:68-81): block powers, BS.1770-4 gating, gain and scaling on the device.
     audio (T,), (T,C) / (C,T), or a batch of stems (S,C,T) (channel-first only) with one target per stem.
     Returns (out like audio, loudness, linear gain, sum(out), sum(audio)) -- scalars, or length-S lists for a batch.
     result_device=True (device tensors only): nothing comes back to the host -- returns (out, res) with res a float64 device tensor
     (S, 4) = {loudness, gain, sum(out), sum(audio)} per stem; the call only enqueues work (a scene generator reads it when it wants).
     want_sumsq=True (with result_device): returns (out, res, sumsq) -- sumsq a float64 device tensor (S,) = sum(out[s] ** 2), accumulated by the
-    pass that writes ``out``; ``mix(..., presums=...)`` takes the speakers' and the noise's entries instead of measuring the stems again."""
+    pass that writes ``out``; ``mix(..., presums=...)`` takes the speakers' and the noise's entries instead of measuring the stems again.
+    cross_speakers=n (2..4, with want_sumsq): the first n stems are the speakers of the mix that follows; sumsq then has S + n (n - 1) / 2 entries, the
+    cross sums sum(out[i] * out[j]) (pairs (0,1), (0,2), (1,2), ...) behind the energies (``ss_lufs_norm_batch_sqx_f32``)."""
     lib = _lib.load()
     coef = np.ascontiguousarray(np.asarray(coef, dtype=np.float64).reshape(2, 6))
     lo = np.ascontiguousarray(np.asarray(lo, dtype=np.int64))
@@ -1115,6 +1125,14 @@ def lufs_norm(audio, coef, lo, hi, block_norm, weights, target_lufs, layout_tc=T
         if not dev:
             raise ValueError("result_device=True needs device tensors")
         res_dev = torch.empty((S, 4), dtype=torch.float64, device=a.device)
+        if want_sumsq and cross_speakers and cross_speakers > 1:
+            npairs = cross_speakers * (cross_speakers - 1) // 2
+            sumsq = torch.empty((S + npairs,), dtype=torch.float64, device=a.device)
+            _lib.check(lib.ss_lufs_norm_batch_sqx_f32(_ptr(a), _ptr(out), T, C, S, int(cross_speakers), coef.ctypes.data_as(_lib.c_f64p),
+                                                      lo.ctypes.data_as(_lib.c_i64p), hi.ctypes.data_as(_lib.c_i64p), nb, float(block_norm),
+                                                      w.ctypes.data_as(_lib.c_f64p), tg.ctypes.data_as(_lib.c_f64p), _ptr(res_dev), _ptr(sumsq),
+                                                      flags | _lib.FLAG_RESULT_DEVICE, stream))
+            return out, res_dev, sumsq
         if want_sumsq:
             sumsq = torch.empty((S,), dtype=torch.float64, device=a.device)
             _lib.check(lib.ss_lufs_norm_batch_sq_f32(_ptr(a), _ptr(out), T, C, S, coef.ctypes.data_as(_lib.c_f64p), lo.ctypes.data_as(_lib.c_i64p),

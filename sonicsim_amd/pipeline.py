@@ -64,8 +64,9 @@ def _normalise_and_mix(stack, fs, nstem, sirs, snr, out, sync=True):
     if sync:
         nstack, gains = A.get_lufs_norm_audio_batch(stack, fs, LUFS_TARGETS[:nstem], allow_many_channels=True, sync=True)
     else:       # round 5: the energy of every normalised stem rides on the pass that writes it -- the mix does not measure the stems again
-        nstack, gains, sq = A.get_lufs_norm_audio_batch(stack, fs, LUFS_TARGETS[:nstem], allow_many_channels=True, sync=False, want_sumsq=True)
-        presums = (sq[:2], sq[3:4])
+        nstack, gains, sq = A.get_lufs_norm_audio_batch(stack, fs, LUFS_TARGETS[:nstem], allow_many_channels=True, sync=False, want_sumsq=True,
+                                                        cross_speakers=2)
+        presums = (sq[:2], sq[3:4]) + ((sq[nstem:nstem + 1],) if sq.numel() == nstem + 1 else ())     # round 6: with the two speakers' cross sum the mix is ONE pass
     normed = [nstack[j] for j in range(nstem)]
     noise = normed[3][None]                                                      # 2-speaker separation mixture; the reference scales the interferer in place
     mix, _ = mixing.mix_sources(nstack[:2], noise, np.asarray(sirs, dtype=np.float32), float(snr), out=out,      # (:113) -- here the stems stay as

@@ -542,3 +542,51 @@ def test_stem_energies_ride_on_the_loudness_pass_and_feed_the_mix(gpu):
     m1, _ = mixing.mix_sources(odd[:2].clone(), odd[3][None], sirs, 12.0, keep_speakers=True)
     m2, _ = mixing.mix_sources(odd[:2].clone(), odd[3][None], sirs, 12.0, keep_speakers=True, presums=(sq_odd[:2], sq_odd[3:4]))
     assert torch.equal(m1, m2)
+
+
+def test_cross_sums_ride_on_the_loudness_pass_and_the_mix_is_one_pass(gpu):
+    """Round 6: ss_lufs_norm_batch_sqx_f32 also leaves the speakers' cross sums sum(out_i * out_j) behind the S energies, and ss_mix_onepass_f32 mixes from
+    them in ONE launch (the energy of the speech sum is the exact quadratic form).  Same normalised stems, records and energies as the plain call; the mix
+    within 1e-6 of the ordinary mix and of the oracle (movingdatamodule.py:105-124) for two and three speakers, with and without the write-back."""
+    from sonicsim_amd import SonicSim_audio as A
+    from sonicsim_amd import mixing
+    from oracle import mix as OM
+    rng = np.random.default_rng(22)
+    S, C, T = 5, 4, 163840
+    base = rng.standard_normal((C, T))
+    stems = (rng.standard_normal((S, C, T)) * np.array([0.05, 0.02, 0.08, 0.01, 0.03])[:, None, None]).astype(np.float32)
+    stems[1] += (0.01 * base).astype(np.float32)             # correlated speakers: the cross terms matter
+    stems[0] += (0.02 * base).astype(np.float32)
+    d = torch.from_numpy(stems).to(gpu)
+    lufs = (-17, -17, -17, -24, -29)
+    np.random.seed(7)
+    o1, r1, sq1 = A.get_lufs_norm_audio_batch(d, 16000, lufs, allow_many_channels=True, sync=False, want_sumsq=True)
+    for nspk in (2, 3):
+        np.random.seed(7)
+        o2, r2, sq = A.get_lufs_norm_audio_batch(d, 16000, lufs, allow_many_channels=True, sync=False, want_sumsq=True, cross_speakers=nspk)
+        npairs = nspk * (nspk - 1) // 2
+        assert sq.numel() == S + npairs
+        assert torch.equal(o1, o2) and torch.equal(r1, r2) and torch.equal(sq[:S], sq1)
+        for b in range(1, nspk):
+            for a in range(b):
+                want = float((o2[a].double() * o2[b].double()).sum())
+                assert abs(float(sq[S + b * (b - 1) // 2 + a]) - want) <= 1e-11 * float(sq1[a].sqrt() * sq1[b].sqrt()), (nspk, a, b)
+        sirs = np.asarray([2.5, -1.0][: nspk - 1], np.float32)
+        for keep in (True, False):
+            a_, b_ = o2[:nspk].clone(), o2[:nspk].clone()
+            m_ref, spk_ref = mixing.mix_sources(a_, o2[3][None], sirs, 12.0, keep_speakers=keep)
+            m_new, spk_new = mixing.mix_sources(b_, o2[3][None], sirs, 12.0, keep_speakers=keep, presums=(sq[:nspk], sq[3:4], sq[S:S + npairs]))
+            torch.cuda.synchronize()
+            den = float(m_ref.double().pow(2).mean().sqrt())
+            assert float((m_new.double() - m_ref.double()).pow(2).mean().sqrt()) / den <= 1e-6
+            assert float((spk_new.double() - spk_ref.double()).abs().max()) <= 1e-6 * float(spk_ref.abs().max())
+            if keep:
+                assert torch.equal(b_, o2[:nspk])                # read-only speakers
+        ref_mix = OM.mix(o2[:nspk].cpu().numpy(), o2[3][None].cpu().numpy(), sirs, 12.0)[0]
+        m_new, _ = mixing.mix_sources(o2[:nspk].clone(), o2[3][None], sirs, 12.0, keep_speakers=True, presums=(sq[:nspk], sq[3:4], sq[S:S + npairs]))
+        assert_parity(m_new.cpu().numpy(), np.asarray(ref_mix), tol=1e-6)
+    # shapes the cross pass does not cover (C * T not a multiple of four) fall back to the energies alone
+    odd = d[:, :3, :-1].contiguous()
+    np.random.seed(7)
+    _, _, sq_odd = A.get_lufs_norm_audio_batch(odd, 16000, lufs, allow_many_channels=True, sync=False, want_sumsq=True, cross_speakers=2)
+    assert sq_odd.numel() == S
