@@ -534,10 +534,10 @@ __device__ __forceinline__ void plan_explicit_body(PlanDevArgs a) {
     if (tid == 0) { a.out[0] = N * a.C; a.out[1] = 0; a.out[2] = 0; a.out[3] = 0; }
     DBG_CLK(3, 1);
     if (tid == 0 && a.status_host) {               // (thread 0 wrote all three words itself)
-        a.status_host[0] = a.call[3];
         a.status_host[1] = a.call[4];
         a.status_host[2] = a.call[2];
-        __threadfence_system();
+        __threadfence_system();                    // word 0 is the flag the host polls (round 6: the validating call returns when the PLANNER has spoken, not
+        __hip_atomic_store(a.status_host, a.call[3], __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);   // when the render has finished): it goes last
     }
 }
 __global__ __launch_bounds__(1024) void k_plan_explicit(PlanDevArgs a) { plan_explicit_body(a); }
@@ -2642,7 +2642,7 @@ int render(int mode, const float* x, int64_t T, const float* bank, int32_t P, in
         pa.call = (int32_t*)c->ws[WS_STATUS];
         pa.status_host = nullptr;
         if (status_out) {
-            if (!c->status_pin) HIPCHK(hipHostMalloc((void**)&c->status_pin, 64, hipHostMallocDefault));
+            if (!c->status_pin) HIPCHK(hipHostMalloc((void**)&c->status_pin, 64, hipHostMallocCoherent));     // (fine-grained: the planner's words are polled while the stream runs on)
             c->status_pin[0] = c->status_pin[1] = c->status_pin[2] = -2;       // (-2: the planner has not reported)
             void* dp = nullptr;
             HIPCHK(hipHostGetDevicePointer(&dp, c->status_pin, 0));
@@ -2988,8 +2988,23 @@ int render(int mode, const float* x, int64_t T, const float* bank, int32_t P, in
     if (status_out) {
         status_out[0] = -1; status_out[1] = 0; status_out[2] = 0;
         if (dev_plan && c->async_status) {
-            HIPCHK(hipStreamSynchronize(stream));
+            // The planner mirrors its verdict into pinned host words ~25 us after the front launch starts; the call returns then and the render kernel
+            // runs on -- device output is ordered by the stream as in every other entry point (round 5 synchronised the stream here: 0.223 ms per
+            // validating call against 0.199 asynchronous).  Host output (below) waits for the render anyway.
             volatile int32_t* sp = c->status_pin;
+            if (sp) {
+                const auto t0 = std::chrono::steady_clock::now();
+                for (int spin = 0; sp[0] == -2; ++spin) {
+                    if ((spin & 63) == 63) {
+                        if (hipStreamQuery(stream) == hipSuccess) break;            // the stream has drained: whatever was written is there
+                        if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) { HIPCHK(hipStreamSynchronize(stream)); break; }
+                    }
+                    __builtin_ia32_pause();
+                }
+                __atomic_thread_fence(__ATOMIC_ACQUIRE);
+            } else {
+                HIPCHK(hipStreamSynchronize(stream));
+            }
             if (sp && sp[0] != -2) {                // the planner's pinned mirror (no copy to wait for)
                 status_out[0] = sp[0]; status_out[1] = (int64_t)sp[1] * DTILE; status_out[2] = sp[2];
             } else {
