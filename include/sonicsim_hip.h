@@ -88,8 +88,11 @@ int ss_plan_status_last(int32_t* out_of_range, int64_t* where, int32_t* too_irre
 /* ss_convolve_moving_f32 with the schedule planned on the device AND this call's verdict returned by the call itself (round 4): status[3] =
  * {out_of_range (1: an interp_index outside [0, P-2]; -1: the engine in use validated on the host before rendering, nothing to report),
  * first sample of the offending 1024-sample tile, too_irregular (the schedule did not fit the planner's task buffer: nothing valid was rendered)}.
- * One synchronisation, taken before the device context's lock is released -- unlike ss_plan_status_last no other thread's render can slip
- * between the render and the read.  This is what ops.convolve_moving(validate=True) calls. */
+ * The verdict is read before the device context's lock is released -- unlike ss_plan_status_last no other thread's render can slip between the render
+ * and the read.  Round 6: the call returns as soon as the PLANNER has reported (it mirrors the verdict into pinned host words which the call polls,
+ * ~25 us after the first launch starts), not when the render has finished: with device pointers y is ordered by the stream like every other entry
+ * point's output (NaN-filled when the verdict is bad); with host pointers the call still returns after the download.  This is what
+ * ops.convolve_moving(validate=True) calls. */
 int ss_convolve_moving_checked_f32(const float* x, int64_t T, const float* rirs, int32_t P, int32_t C, int32_t L, const int64_t* idx,
                                    const float* w, float* y, uint32_t flags, void* stream, int64_t* status);
 
