@@ -892,6 +892,9 @@ def run_scenes(args, rank, local_rank, world, dev):
             gains.append(rend.render(spec, seed=base + j, sirs=sir, snr=snr, out=out, sync=False, next_scene=nxt)[1])      # (5,) float64 on the device: no wait per scene
             if sg is not None:
                 sg.submit(j)
+            if os.environ.get("BENCH_SCENE_EVENTS"):                       # (lab: per-scene GPU and host times of the loop)
+                e_ = torch.cuda.Event(enable_timing=True); e_.record()
+                run.evs = getattr(run, "evs", []) + [(e_, time.perf_counter())]
         run.gains = A.lufs_gains_from_result(torch.stack(gains).cpu().numpy()) if gains else None    # every scene's five loudness gains reach the host inside the timed region
         return sg.finish() if sg is not None else None
 
@@ -902,22 +905,33 @@ def run_scenes(args, rank, local_rank, world, dev):
         del calib
         torch.cuda.synchronize()
     lo = parallel.shard_range(total, rank, world)[0] if total else 0
+    # the timed run's gather array exists BEFORE the warm-up: its allocation (2 GB at 64 scenes) would otherwise sit between the warm-up and the timed
+    # scenes and let the clocks fall back
+    sg_early = parallel.make_gather(args.gather, total, (pool[0].C, pool[0].T), device=dev) if gather else None
     gw = parallel.make_gather(args.gather, max(1, args.warmup) * world, (pool[0].C, pool[0].T), device=dev) if gather else None
     run(max(1, args.warmup), gw, 10_000_000)
     if hasattr(gw, "close"):
         torch.cuda.synchronize()
         gw.close()
     torch.cuda.synchronize()
-    sg = parallel.make_gather(args.gather, total, (pool[0].C, pool[0].T), device=dev) if gather else None
+    sg = sg_early
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    run.evs = []
     res = run(per_rank, sg, lo)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     dt = parallel.barrier_max_seconds(time.perf_counter() - t0, device=dev)
+    if os.environ.get("BENCH_SCENE_EVENTS") and run.evs:
+        ge = [a[0].elapsed_time(b[0]) * 1e3 for a, b in zip(run.evs[:-1], run.evs[1:])]
+        he = [(b[1] - a[1]) * 1e6 for a, b in zip(run.evs[:-1], run.evs[1:])]
+        print("[lab] per-scene GPU us:", " ".join("%.0f" % v for v in ge), file=sys.stderr)
+        print("[lab] per-scene host us:", " ".join("%.0f" % v for v in he), file=sys.stderr)
+        print("[lab] host enqueue of all scenes finished %.1f ms after t0; GPU finished %.1f ms after t0" % ((run.evs[-1][1] - t0) * 1e3, dt * 1e3), file=sys.stderr)
+        run.evs = []
     cfg3 = None
     if world == 1 and gather and not os.environ.get("BENCH_IN_PMC"):       # config 3 = the same scenes with no gather: its own figure (VERDICT r4 missing 5)
         n3 = min(16, per_rank)
@@ -1464,7 +1478,9 @@ def secondary_legs(args, rank, local_rank, dev, primary):
 
     def cfg4():
         a = copy.copy(args)
-        a.config, a.steps, a.warmup = "cfg4", 64, 2
+        a.config, a.steps, a.warmup = "cfg4", 64, 16     # (16 untimed scenes: the host runs several scenes ahead of the GPU at first and grows its ring of pinned
+                                                          #  plan buffers -- ~1 ms of hipHostMalloc each, scenes 3-5 of a 2-scene warm-up -- and the clocks take
+                                                          #  ~15 ms of scenes to settle: 1.05 ms per scene at first, 0.92 sustained; profiles/r06ax)
         cb = (primary.get("cpu_baseline") or {})
         a.cfg2_cpu_seconds = cb.get("seconds_measured") if "whole config" in str(cb.get("sample", "")) else None
         return run_scenes(a, rank, local_rank, 1, dev)

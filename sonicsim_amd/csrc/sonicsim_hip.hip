@@ -4638,6 +4638,8 @@ int ss_gather_create(void** handle, int64_t num_scenes, int64_t scene_bytes, voi
     memcpy(ipc_handle_out, &h, sizeof(h));
     if (hipStreamCreateWithFlags(&g->copy, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&g->ev_in, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&g->ev_out, hipEventDisableTiming) != hipSuccess) { hipFree(g->base); delete g; return fail(SS_EHIP, "stream / event creation failed"); }
+    (void)hipEventRecord(g->ev_out, g->copy);          // a stream gets its hardware queue on first use (milliseconds): here, not inside the caller's first scene
+    (void)hipStreamSynchronize(g->copy);
     *handle = g;
     return SS_OK;
 }
@@ -4653,6 +4655,8 @@ int ss_gather_attach(void** handle, const void* ipc_handle_in, int64_t num_scene
     if (e != hipSuccess) { delete g; return fail(SS_EHIP, "hipIpcOpenMemHandle failed: %s", hipGetErrorString(e)); }
     if (hipStreamCreateWithFlags(&g->copy, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&g->ev_in, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&g->ev_out, hipEventDisableTiming) != hipSuccess) { hipIpcCloseMemHandle(g->base); delete g; return fail(SS_EHIP, "stream / event creation failed"); }
+    (void)hipEventRecord(g->ev_out, g->copy);          // (first use of the copy stream: see ss_gather_create)
+    (void)hipStreamSynchronize(g->copy);
     *handle = g;
     return SS_OK;
 }

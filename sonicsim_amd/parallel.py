@@ -104,6 +104,11 @@ class SceneGather:
             self.result = None
             self.send = [torch.empty(tuple(shape), dtype=dtype, device=device) for _ in range(depth)]
         self.side = torch.cuda.Stream(device=device) if self.cuda else None
+        if self.side is not None:
+            # a HIP stream gets its hardware queue on FIRST USE, and that costs milliseconds (5.5 ms measured, profiles/r06ax: a gather object made right
+            # before a timed window paid it inside the window -- 90 us per scene of a 64-scene run): use the stream once here
+            torch.cuda.Event().record(self.side)
+            self.side.synchronize()
         self.done = [None] * depth                       # event of the transfer that last used send buffer b
 
     def steps(self) -> int:
@@ -158,7 +163,7 @@ class SceneGather:
 
     def finish(self):
         """all transfers are complete on return of the next synchronisation of the current stream"""
-        if self.cuda:
+        if self.cuda and self.on:
             self.torch.cuda.current_stream().wait_stream(self.side)
         return self.result
 

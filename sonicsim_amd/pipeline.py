@@ -155,8 +155,8 @@ class SceneRenderer:
         if self._sets[si] is not None:
             torch.cuda.synchronize(self.device)      # rare (the scene shapes changed): nothing of the old set is in flight when it goes back to the allocator
             self._set_free[si] = None
-        banks = [torch.empty((P, spec.C, spec.L), dtype=torch.float32, device=self.device) for _ in range(3)] + \
-                [torch.empty((1, spec.C, spec.L), dtype=torch.float32, device=self.device) for _ in range(2)]
+        banks = [torch.empty((P, spec.C, spec.L), dtype=torch.float32, device=self.device) for _ in range(3)]
+        banks = banks + [torch.empty((1, spec.C, spec.L), dtype=torch.float32, device=self.device) for _ in range(2)]
         peaks = [torch.empty(1, dtype=torch.float32, device=self.device) for _ in range(3)]
         self._sets[si] = (banks, peaks)
 
