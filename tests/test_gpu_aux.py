@@ -32,6 +32,26 @@ def test_rir_bank_synth_matches_numpy_definition(gpu):
     assert 0.8 < c01 < 0.97 and abs(c06) < 0.65
 
 
+def test_rir_bank_synth_geometry_paths(gpu):
+    """round 6: the generator keeps the geometry of a workgroup's channel(s) in LDS (<= 2 048 (position, channel) pairs) and runs an ungated loop for the
+    waves behind every direct-path delay.  Shapes that take the other paths: more positions than the LDS table holds (global loads in the loop), rows so
+    short that a workgroup spans many channels, an odd L (one tap per thread), delays beyond the taps (every wave gated) -- all against the NumPy definition,
+    peaks included."""
+    from sonicsim_amd import ops
+    for (P, C, L, far) in ((1100, 2, 600, False), (40, 8, 100, False), (9, 3, 777, False), (5, 2, 4096, True), (300, 8, 1536, False)):
+        src = OR.random_walk(P, 33 + P)
+        mics = np.array([5.0, 1.5, 4.0]) + OR.circular_array(C)
+        if far:
+            mics = mics + np.array([60.0, 0.0, 0.0])                  # direct paths of ~2 800 samples: most of the 4 096 taps are gated
+        delay, dgain = OR.delays_and_gains(src, mics, 16000)
+        ref = OR.rir_bank_synth(delay, dgain, L, 16000, 0.45, 77 + P)
+        got, pk = ops.rir_bank_synth(delay, dgain, L, 16000, 0.45, 77 + P, device=gpu, return_peak=True)
+        g = got.cpu().numpy()
+        assert np.abs(g - ref).max() < 2e-5 * np.abs(ref).max(), (P, C, L)
+        assert rel_rms(g, ref) < 1e-5, (P, C, L)
+        assert float(pk.cpu().numpy().reshape(-1)[0]) == float(np.abs(g).max()), (P, C, L)
+
+
 def test_peak_normalize_bit_exact(gpu):
     from sonicsim_amd import ops
     rng = np.random.default_rng(4)
