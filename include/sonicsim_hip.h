@@ -48,6 +48,7 @@ extern "C" {
 #define SS_FLAG_BANK_DEVICE 0x8000u /* render entry points WITHOUT SS_FLAG_DEVICE_PTR: `rirs` alone is a DEVICE pointer (a resident bank rendered for a host dry signal into a host array) */
 #define SS_FLAG_ROW_SPECTRA 0x10000u /* render entry points, assembly engine: transform EVERY filter row once in a pre-pass (default: only rows cut into >= 5 tasks, i.e. trajectories of few points, and static sources; csrc/plan.h flag_long_rows) */
 #define SS_FLAG_NO_ROW_SPECTRA 0x20000u /* ... never: every task transforms its row's taps itself (the only form before round 6) */
+#define SS_FLAG_BACKGROUND 0x40000u /* ss_rir_bank_synth_batch_f32: the launch runs BESIDE another stream's kernels (a scene's loudness / mix while the next scene's banks are generated): at most five workgroups per CU instead of eight, so that the other stream's workgroups find wave slots (a scene -3.5 %; the launch alone +4 %) */
 #define SS_FLAG_ASYNC_PLAN 0x800u /* ss_convolve_moving_f32 with device pointers: plan the explicit schedule on the device (no host synchronisation) */
 
 int ss_version(void);

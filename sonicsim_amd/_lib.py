@@ -27,6 +27,7 @@ FLAG_KEEP_SPEAKERS = 0x4000
 FLAG_BANK_DEVICE = 0x8000
 FLAG_ROW_SPECTRA = 0x10000
 FLAG_NO_ROW_SPECTRA = 0x20000
+FLAG_BACKGROUND = 0x40000
 
 SS_EINVAL, SS_EHIP, SS_ENOMEM, SS_ENODEV = -1, -2, -3, -4
 

@@ -3681,8 +3681,14 @@ int ss_rir_bank_synth_batch_f32(int32_t n, const SsRirParams* prm, float* const*
         tab.peak[b] = (peaks && peaks[b]) ? reinterpret_cast<unsigned int*>(peaks[b]) : nullptr;
         tab.slots[b] = (unsigned int*)c->ws[WS_K1] + per * (size_t)b;
     }
-    if (vec4) hipLaunchKernelGGL((k_rir_synth_batch<4>), dim3(gx, (unsigned)n), dim3(256), 0, stream, tab);
-    else hipLaunchKernelGGL((k_rir_synth_batch<2>), dim3(gx, (unsigned)n), dim3(256), 0, stream, tab);
+    // SS_FLAG_BACKGROUND: 16 000 B of dynamic LDS nobody touches cap the generator at five workgroups per CU (eight by its wave slots), so that the kernels of
+    // another stream -- a scene's loudness / mix while the NEXT scene's banks are generated -- find wave slots: a generator workgroup lives for the whole
+    // launch (every thread walks all positions), the short kernels beside it otherwise queue behind it.  A scene 0.957-0.967 -> 0.928-0.933 ms; the five-bank
+    // launch alone 186 -> 194 us (profiles/r06az; tuning knob SS_K1_LDS_PAD overrides the bytes).
+    static const int k1_pad_knob = knob("SS_K1_LDS_PAD") ? atoi(knob("SS_K1_LDS_PAD")) : -1;
+    const int k1_pad = k1_pad_knob >= 0 ? k1_pad_knob : ((flags & SS_FLAG_BACKGROUND) ? 16000 : 0);
+    if (vec4) hipLaunchKernelGGL((k_rir_synth_batch<4>), dim3(gx, (unsigned)n), dim3(256), (size_t)k1_pad, stream, tab);
+    else hipLaunchKernelGGL((k_rir_synth_batch<2>), dim3(gx, (unsigned)n), dim3(256), (size_t)k1_pad, stream, tab);
     HIPCHK(hipGetLastError());
     return SS_OK;
 }

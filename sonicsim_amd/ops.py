@@ -865,10 +865,11 @@ def rir_bank_synth(delay, dgain, L, fs, rt60, seed, tail_gain=0.05, rho=0.9, dev
 
 
 @_restores_device
-def rir_bank_synth_batch(geoms, L, fs, outs, peaks=None, tail_gain=0.05, rho=0.9):
+def rir_bank_synth_batch(geoms, L, fs, outs, peaks=None, tail_gain=0.05, rho=0.9, background=False):
     """Row R for the banks of one scene in ONE launch (``ss_rir_bank_synth_batch_f32``).  geoms: list of (delay, dgain, rt60, seed) with
     delay / dgain contiguous int32 / float32 (P_i, C) DEVICE tensors; outs[i]: contiguous float32 (P_i, C, L) device tensor to fill;
-    peaks[i]: one-element float32 device tensor or None.  Same values as ``rir_bank_synth`` bank by bank."""
+    peaks[i]: one-element float32 device tensor or None.  Same values as ``rir_bank_synth`` bank by bank.
+    background=True (``SS_FLAG_BACKGROUND``): the launch runs beside another stream's kernels and leaves them wave slots."""
     import torch
     n = len(geoms)
     if not (1 <= n <= 8) or len(outs) != n or (peaks is not None and len(peaks) != n):
@@ -894,7 +895,8 @@ def rir_bank_synth_batch(geoms, L, fs, outs, peaks=None, tail_gain=0.05, rho=0.9
                 raise ValueError("a peak must be a one-element float32 tensor on the banks' device")
         pk = vp(*[ctypes.c_void_p(p.data_ptr()) if p is not None else None for p in peaks])
     _set_device(outs[0])
-    _lib.check(_lib.load().ss_rir_bank_synth_batch_f32(n, prm, ob, pk, _lib.FLAG_DEVICE_PTR | _lib.FLAG_META_DEVICE, _stream_ptr(outs[0])))
+    _lib.check(_lib.load().ss_rir_bank_synth_batch_f32(n, prm, ob, pk, _lib.FLAG_DEVICE_PTR | _lib.FLAG_META_DEVICE | (_lib.FLAG_BACKGROUND if background else 0),
+                                                       _stream_ptr(outs[0])))
     return outs
 
 

@@ -160,11 +160,11 @@ class SceneRenderer:
         peaks = [torch.empty(1, dtype=torch.float32, device=self.device) for _ in range(3)]
         self._sets[si] = (banks, peaks)
 
-    def _provide(self, spec, seed, si):
+    def _provide(self, spec, seed, si, background=False):
         banks, peaks = self._sets[si]
         geoms = [(delay, dgain, rt60, (seed * 8 + k) & 0x7FFFFFFF) for k, (x, delay, dgain, seg, rt60) in enumerate(spec.speakers)] + \
                 [(delay, dgain, rt60, (seed * 8 + 4 + k) & 0x7FFFFFFF) for k, (x, delay, dgain, rt60) in enumerate(spec.statics)]
-        ops.rir_bank_synth_batch(geoms, spec.L, spec.fs, banks, list(peaks) + [None, None])      # the five banks of the scene: ONE launch
+        ops.rir_bank_synth_batch(geoms, spec.L, spec.fs, banks, list(peaks) + [None, None], background=background)      # the five banks of the scene: ONE launch
         return banks, peaks
 
     def prefetch(self, spec: SceneSpec, seed: int):
@@ -184,7 +184,7 @@ class SceneRenderer:
         for t in self._sets[si][0] + self._sets[si][1]:
             t.record_stream(self._k1_stream)                       # written by the side stream, read by the caller's
         with torch.cuda.stream(self._k1_stream):
-            self._provide(spec, seed, si)
+            self._provide(spec, seed, si, background=True)       # beside the current scene's loudness / mix: leave them wave slots
             ev = torch.cuda.Event()
             ev.record(self._k1_stream)
         self._ready = ((spec, int(seed)), si, ev)                  # the spec OBJECT (kept alive), not its id(): an id can be reused after a collection
