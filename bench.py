@@ -660,7 +660,8 @@ def run_cfg2(args, rank, local_rank, world, dev):
     # ---- the plain loop a user of the drop-in writes: SonicSim_moving.interpolate_moving_audio on ROCm tensors, no block, no out= --
     #      round 6's implicit overlap puts the renders on alternating side streams by itself; the same loop with the overlap switched off beside it
     dropin = None
-    if world == 1 and args.config == "cfg2" and not os.environ.get("BENCH_IN_PMC"):
+    if world == 1 and args.config == "cfg2" and not os.environ.get("BENCH_IN_PMC") and not getattr(args, "serial", False):
+        # (a --serial run is a profiler pass -- tools/profile.sh --: ONE stream throughout, so that a kernel-trace average is the kernel alone)
         try:
             from sonicsim_amd import SonicSim_moving as M
             xs1, irs, posl = x[None], bank[:, None], list(sc.positions)
