@@ -4,7 +4,8 @@ import ctypes, sys
 import numpy as np, torch
 sys.path.insert(0, ".")
 from sonicsim_amd import _lib
-_lib.use_library("sonicsim_amd/lib/libsonicsim_hip_dbgclk.so")
+import os
+_lib.use_library(os.environ.get("BENCH_LIB") or "sonicsim_amd/lib/libsonicsim_hip_dbgclk.so")
 from oracle import moving as O
 from sonicsim_amd import ops, synth
 ops.init(0)
@@ -20,10 +21,11 @@ for cfg in ("cfg2", "cfg5"):
         ops.convolve_moving(x, bank, di, dw, out=out, validate=False)
     torch.cuda.synchronize()
     lib = ctypes.CDLL(_lib.load()._name)
-    buf = (ctypes.c_ulonglong * (8 * 2 * 256))()
+    buf = (ctypes.c_ulonglong * (12 * 2 * 256))()
     lib.ss_debug_clk(buf)
-    a = np.frombuffer(buf, dtype=np.uint64).reshape(8, 2, 256).astype(np.int64)
-    t = [a[0, 0, 0], a[0, 1, 0], a[1, 0, 0], a[1, 1, 0], a[2, 0, 0], a[2, 1, 0], a[3, 0, 0], a[3, 1, 0]]
+    a = np.frombuffer(buf, dtype=np.uint64).reshape(12, 2, 256).astype(np.int64)
+    g = int(np.argmax(a[3, 1, :]))            # the workgroup that ran the planner: 0 as its own launch, n_mm inside k_front_explicit (round 6)
+    t = [a[0, 0, g], a[0, 1, g], a[1, 0, g], a[1, 1, g], a[2, 0, g], a[2, 1, g], a[3, 0, g], a[3, 1, g]]
     names = ["phase 1 (block bounds)", "phase 2 (first/last)", "phase 3 + scan", "phase 4 (emit row-tasks)", "keys + crange + bins zero + scan keys", "ranges + scan bins", "placement + stores"]
-    print(cfg, " | ".join(f"{n} {(t[i + 1] - t[i]) / 100.0:.2f} us" for i, n in enumerate(names)), f"| total {(t[-1] - t[0]) / 100.0:.2f} us", flush=True)
+    print(cfg, " | ".join(f"{n} {(t[i + 1] - t[i]) / 100.0:.2f} us" for i, n in enumerate(names)), f"| total {(t[-1] - t[0]) / 100.0:.2f} us (workgroup {g})", flush=True)
     del bank, x, out
