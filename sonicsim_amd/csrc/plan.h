@@ -191,20 +191,6 @@ inline void merge_lpt_xcd(Plan& plan, int NP, int groups, std::vector<Task>& out
 // multiple of that hop instead of a multiple of `block` -- a row of 2.3 blocks then never spills into a fourth block and fewer
 // rows need a second task.  Task::j0 is in HOP units (first sample = j0 * (block >> rs)); blocks of a task stay `block` apart.
 inline int g_plan_balanced = 1;
-// Round 6: piece count of LONG rows (>= g_plan_piece_min tasks: the rows flag_long_rows marks, whose tasks only load spectra) scaled by g_plan_piece_scale >= 1,
-// set by the caller for one plan_seg_lpt call (fill_rounds below): N equal tasks on W persistent workgroups take ceil(N / W) task-times although only N / W
-// are needed -- cutting the same rows into the NEXT multiple of W pieces makes every workgroup's share equal AND every piece smaller.
-inline thread_local double g_plan_piece_scale = 1.0;
-inline thread_local int g_plan_piece_min = 5;
-inline int64_t row_piece_count(int64_t nb, int jmax) {
-    int64_t ntask = (nb + jmax - 1) / jmax;
-    if (g_plan_piece_scale > 1.0 && ntask >= g_plan_piece_min) {
-        int64_t n2 = (int64_t)((double)ntask * g_plan_piece_scale + 0.999999);
-        if (n2 > nb) n2 = nb;
-        if (n2 > ntask) ntask = n2;
-    }
-    return ntask;
-}
 template <class F> inline void row_tasks(int64_t a0, int64_t a2, int block, int jmax, int rs, F f) {
     if (a2 <= a0) return;
     const int64_t hop = block >> rs;
@@ -223,52 +209,12 @@ template <class F> inline void row_tasks(int64_t a0, int64_t a2, int block, int 
         }
         return;
     }
-    const int64_t ntask = row_piece_count(nb, jmax);
+    const int64_t ntask = (nb + jmax - 1) / jmax;
     for (int64_t k = 0; k < ntask; ++k) {
         const int nj = (int)(nb / ntask + (k < nb % ntask ? 1 : 0));
         f((int)jh, nj);
         jh += (int64_t)nj << rs;
     }
-}
-
-// The piece scale that brings the task count of a segment schedule to (at most) the next multiple of nwg.  Returns 1.0 when nothing is to gain: no long
-// row, the count already a multiple, or a long row that will NOT be transformed once (its spectra exceed `budget_bytes`: finer pieces would multiply its
-// forward transforms).  rs = 0 schedules only (the hop-unit starts of the short-row planner never meet long rows).
-inline double fill_rounds_scale(const std::vector<int64_t>& seg_start, int P, int C, int block, int jmax, int NP, int nwg, int min_tasks, int64_t budget_bytes,
-                                int max_rows) {
-    if (nwg < 1 || P < 1) return 1.0;
-    auto count = [&](double scale, int64_t* nlong, int64_t* long_rows) {
-        const double keep_s = g_plan_piece_scale;
-        const int keep_m = g_plan_piece_min;
-        g_plan_piece_scale = scale;
-        g_plan_piece_min = min_tasks;
-        int64_t n = 0, nl = 0, lr = 0;
-        for (int r = 0; r < P; ++r) {
-            const int64_t a0 = seg_start[r > 0 ? r - 1 : r], a2 = seg_start[r < P - 1 ? r + 1 : r];
-            int64_t k = 0;
-            row_tasks(a0, a2, block, jmax, 0, [&](int, int) { ++k; });
-            n += k * C;
-            if (a2 > a0 && ((a2 - (a0 / block) * block + block - 1) / block + jmax - 1) / jmax >= min_tasks) { nl += k * C; ++lr; }
-        }
-        g_plan_piece_scale = keep_s;
-        g_plan_piece_min = keep_m;
-        if (nlong) *nlong = nl;
-        if (long_rows) *long_rows = lr;
-        return n;
-    };
-    int64_t nlong = 0, long_rows = 0;
-    const int64_t n0 = count(1.0, &nlong, &long_rows);
-    if (nlong == 0 || n0 <= 0) return 1.0;
-    if (long_rows > max_rows || long_rows * (int64_t)C * NP * block * 8 > budget_bytes) return 1.0;      // (flag_long_rows would leave some of them transforming)
-    const int64_t w = n0 < nwg ? n0 : nwg;
-    const int64_t target = (n0 + w - 1) / w * w;
-    if (target == n0) return 1.0;
-    double lo = 1.0, hi = 1.0 + (double)(target - n0) / (double)nlong * 1.5 + 0.5;
-    for (int it = 0; it < 40; ++it) {
-        const double mid = 0.5 * (lo + hi);
-        if (count(mid, nullptr, nullptr) <= target) lo = mid; else hi = mid;
-    }
-    return count(lo, nullptr, nullptr) > n0 ? lo : 1.0;
 }
 
 inline void plan_seg_lpt(const std::vector<int64_t>& seg_start /*[P], last == T*/, int P, int C, int block, int jmax, int NP,

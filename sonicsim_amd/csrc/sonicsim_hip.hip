@@ -2695,23 +2695,8 @@ int render(int mode, const float* x, int64_t T, const float* bank, int32_t P, in
         (void)plan_split;
         static const int plan_pair = knob("SS_PLAN_PAIR") ? atoi(knob("SS_PLAN_PAIR")) : 1;       // tasks of one row adjacent in the queue (plan.h; tuning build: 0 = by their own cost)
         const bool two_level = g14 && c->dynq && plan_groups == 8 && !chunked;
-        // rows that will be transformed once (hrow_mark below) are cut into as many pieces as fill the persistent workgroups' rounds exactly (plan.h
-        // fill_rounds_scale): P = 12 at config-2 shapes 1 056 tasks of four blocks on 256 workgroups = five task-times for 4.1 rounds of work -> 1 232 tasks of
-        // three or four blocks (tuning knob SS_PLAN_FILL=0: off)
-        static const int plan_fill = knob("SS_PLAN_FILL") ? atoi(knob("SS_PLAN_FILL")) : 1;
-        double piece_scale = 1.0;
-        if (plan_fill && g14 && !chunked && rs == 0 && !(flags & SS_FLAG_NO_ROW_SPECTRA)) {
-            static const int hrow_min_f = knob("SS_HROW_MIN") ? atoi(knob("SS_HROW_MIN")) : 5;
-            static const int64_t hrow_mb_f = knob("SS_HROW_MB") ? atoll(knob("SS_HROW_MB")) : 96;
-            const bool force = (flags & SS_FLAG_ROW_SPECTRA) != 0;
-            piece_scale = fill_rounds_scale(c->seg_start, P, C, BB, JM, NPart, c->num_cu, force ? 1 : hrow_min_f, force ? ((int64_t)1 << 40) : (hrow_mb_f << 20), HROW_MAX);
-            g_plan_piece_min = force ? 1 : hrow_min_f;
-        }
-        g_plan_piece_scale = piece_scale;
         plan_seg_lpt(c->seg_start, P, C, BB, JM, NPart, c->plan.tasks[0], c->plan_scratch, (g14 && plan_groups > 1 && plan_groups <= 64) ? plan_groups : 1,
                      (plan_snake && !two_level) ? c->num_cu : 0, rs, two_level ? plan_tail : 0, &qmain, plan_pair != 0);
-        g_plan_piece_scale = 1.0;
-        g_plan_piece_min = 5;
         c->plan.tasks[1].clear();
         if (chunked) {      // stable counting sort of the list by the chunk of the task's row (the LPT / XCD order survives inside a chunk)
             std::vector<Task>& tk = c->plan.tasks[0];

@@ -174,36 +174,6 @@ int emul_plan_prop(const int64_t* seg_len, int P, int C, int L, int jmax, int gr
     return (int)t.size();
 }
 
-// round 6: the same planner with the long rows cut into as many pieces as fill the workgroups' rounds (plan.h fill_rounds_scale, the library's render()):
-// returns the task count, *scale_out = the piece scale used (1.0: nothing to gain), *n_plain = the count without it
-int emul_plan_fill(const int64_t* seg_len, int P, int C, int L, int jmax, int nwg, int hrow_min, int64_t hrow_budget, int32_t* out, int max_tasks,
-                   double* scale_out, int32_t* n_plain, int32_t* nrows_out) {
-    std::vector<int64_t> seg_start(P);
-    int64_t s = 0;
-    for (int k = 0; k < P - 1; ++k) { seg_start[k] = s; s += seg_len[k]; }
-    seg_start[P - 1] = s;
-    const int NP = (L + B12 - 1) / B12;
-    std::vector<Task> t;
-    std::vector<int32_t> scratch;
-    int32_t m = -1;
-    plan_seg_lpt(seg_start, P, C, B12, jmax, NP, t, scratch, 8, 0, 0, 12, &m, true);
-    if (n_plain) *n_plain = (int32_t)t.size();
-    const double sc = fill_rounds_scale(seg_start, P, C, B12, jmax, NP, nwg, hrow_min, hrow_budget, HROW_MAX);
-    if (scale_out) *scale_out = sc;
-    g_plan_piece_scale = sc;
-    g_plan_piece_min = hrow_min;
-    plan_seg_lpt(seg_start, P, C, B12, jmax, NP, t, scratch, 8, 0, 0, 12, &m, true);
-    g_plan_piece_scale = 1.0;
-    g_plan_piece_min = 5;
-    std::vector<int32_t> rows;
-    const int32_t Pone = P;
-    const int nr = flag_long_rows(t, &Pone, 1, C, NP, hrow_min, hrow_budget, HROW_MAX, rows);
-    if (nrows_out) *nrows_out = nr;
-    const int n = (int)std::min<size_t>(t.size(), (size_t)max_tasks);
-    for (int i = 0; i < n; ++i) { out[4 * i] = t[i].row; out[4 * i + 1] = t[i].chan; out[4 * i + 2] = t[i].j0; out[4 * i + 3] = t[i].nj; }
-    return (int)t.size();
-}
-
 // the host planner of an EXPLICIT (idx, w) schedule as the library runs it for the assembly engine (sonicsim_hip.hip render(): per-tile min / max of
 // idx, build_plan, merge_lpt_xcd -- the host twin of k_plan_explicit) + the long-row marking
 int emul_plan_explicit(const int64_t* idx, int64_t T, int P, int C, int L, int jmax, int groups, int hrow_min, int64_t hrow_budget, int32_t* out,

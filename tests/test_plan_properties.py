@@ -34,8 +34,6 @@ def _lib():
     lib = ctypes.CDLL(out)
     lib.emul_plan_prop.argtypes = [ip, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                    ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_int, i32, i32, ctypes.c_int, i32, i32]
-    lib.emul_plan_fill.argtypes = [ip, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int64, i32, ctypes.c_int,
-                                   ctypes.POINTER(ctypes.c_double), i32, i32]
     lib.emul_plan_explicit.argtypes = [ip, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                        ctypes.c_int64, i32, ctypes.c_int, i32]
     return lib
@@ -177,82 +175,6 @@ def test_a_task_array_cap_would_be_caught():
     covered = sum(int(t[i, 3] & NJ_MASK) for i in keep)
     want = sum(-(-int(a2) // B) - int(a0) // B for a0, a2 in ((0, 500000), (0, 1000000), (500000, 1000000)))
     assert covered < want == sum(int(k & NJ_MASK) for k in t[:, 3])
-
-
-# ----------------------------------------------------------------------------------------- long rows cut to fill the workgroups' rounds (round 6)
-def plan_fill(seg, P, C, L, jmax, nwg, hmin, budget):
-    seg = np.ascontiguousarray(seg, np.int64)
-    cap = 1 << 15
-    while True:
-        out = np.zeros((cap, 4), np.int32)
-        sc, n0, nr = ctypes.c_double(0), ctypes.c_int32(0), ctypes.c_int32(0)
-        n = LIB.emul_plan_fill(seg.ctypes.data_as(ip), P, C, L, jmax, nwg, hmin, budget, out.ctypes.data_as(i32), cap, ctypes.byref(sc), ctypes.byref(n0),
-                               ctypes.byref(nr))
-        if n <= cap:
-            return out[:n].astype(np.int64), float(sc.value), int(n0.value), int(nr.value)
-        cap = n
-
-
-fill_case = st.integers(2, 40).flatmap(lambda P: st.tuples(
-    st.just(P),
-    st.lists(st.one_of(st.integers(1, 3000), st.integers(20000, 400000), st.integers(100000, 1200000)), min_size=P - 1, max_size=P - 1),
-    st.integers(1, 8),                                   # C
-    st.sampled_from([4096, 9000, 20000, 48000, 96000]),  # L
-    st.sampled_from([8, 64, 256, 304]),                  # persistent workgroups
-    st.sampled_from([3, 5, 5, 9]),                       # hrow_min
-    st.sampled_from([1 << 40, 96 << 20, 8 << 20])))      # spectra budget
-
-
-@settings(max_examples=600, deadline=None, suppress_health_check=list(HealthCheck), derandomize=True)
-@given(fill_case)
-def test_fill_rounds_keeps_the_tiling_and_lands_on_a_multiple(case):
-    """plan.h fill_rounds_scale: the long rows (>= hrow_min tasks, all of them transformed once) cut into more, smaller pieces so that the task count is at
-    most the next multiple of the workgroup count.  Same exact tiling of every row as the plain plan, never MORE than that multiple, never fewer tasks than
-    the plain plan, short rows untouched, and nothing changes when a long row would not be transformed once (budget) or the count already fits."""
-    P, seg, C, L, nwg, hmin, budget = case
-    seg = np.array(seg, np.int64)
-    if seg.sum() >= 1 << 28:
-        seg = seg // 8
-    t, scale, n0, nrows = plan_fill(seg, P, C, L, 4, nwg, hmin, budget)
-    n = len(t)
-    start = np.concatenate([[0], np.cumsum(seg)]).astype(np.int64)
-    nj = t[:, 3] & NJ_MASK
-    assert ((nj >= 1) & (nj <= 4)).all()
-    per = {}
-    for (row, chan, j0, _), k in zip(t, nj):
-        per.setdefault((int(row), int(chan)), []).append((int(j0), int(k)))
-    plain_tasks, long_rows = 0, 0
-    for r in range(P):
-        a0 = start[r - 1] if r > 0 else start[r]
-        a2 = start[r + 1] if r < P - 1 else start[r]
-        nb = -(-(a2 - (a0 // B) * B) // B) if a2 > a0 else 0
-        base = -(-nb // 4)
-        plain_tasks += base * C
-        is_long = base >= hmin
-        long_rows += is_long
-        for c in range(C):
-            got = sorted(per.get((r, c), []))
-            if a2 <= a0:
-                assert not got
-                continue
-            pos = (a0 // B) * B
-            for j0, k in got:
-                assert j0 * B == pos, (r, c, got)
-                pos += k * B
-            assert pos >= a2 and pos - B < a2
-            if not is_long or scale == 1.0:
-                assert len(got) == base, (r, c, len(got), base)          # short rows: the fewest tasks, as ever
-            else:
-                assert base <= len(got) <= nb
-    assert n0 == plain_tasks
-    w = min(n0, nwg)
-    target = -(-n0 // w) * w
-    assert n0 <= n <= target, (n0, n, target, scale)
-    if scale > 1.0:
-        assert n > n0 and nrows == long_rows                 # every long row is transformed once
-        assert target - n < max(C * long_rows, 1) + C        # as close to the multiple as whole pieces of rows allow
-    else:
-        assert n == n0
 
 
 # ----------------------------------------------------------------------------------------- explicit (idx, w) schedules
