@@ -2565,8 +2565,10 @@ int render(int mode, const float* x, int64_t T, const float* bank, int32_t P, in
     if (flags & SS_FLAG_GEOM_13) geom = 13;
     const bool g13 = use_os && T < ((int64_t)1 << 30) && (int64_t)L * 4 < ((int64_t)1 << 31) && geom == 13;
     const bool g14 = use_os && T < ((int64_t)1 << 30) && (int64_t)L * 4 < ((int64_t)1 << 31) &&
-                     (geom == 14 || (flags & SS_FLAG_GEOM_ASM) || (geom == 0 && L > 2 * B));   // hand-scheduled assembly engine (k_os13_asm):
-                                                                                                // the default for long filters
+                     (geom == 14 || (flags & SS_FLAG_GEOM_ASM) || geom == 0);   // hand-scheduled assembly engine (k_os13_asm): the default whenever the
+                                                                                 // transform engine is (L > 128).  Until round 6 only for L > 4096; it is
+                                                                                 // 0.23-0.94 x the B = 2048 engine's time on every shorter shape tried
+                                                                                 // (static and moving, T = 16 000 .. 960 000: profiles/r06cc)
     const bool g12 = g13 || g14 || (use_os && T < ((int64_t)1 << 30) && geom == 12);     // 13/14 share 12's block size, spectra and plan
     if (g14 && (rc = load_mod13(c, c->dynq))) return rc;
     if (xdiv && !(g13 || g14)) {       // engines without the fused scaling: divide a copy of x (linear in x)
