@@ -171,7 +171,7 @@ int ss_convolve_moving_seg_div_f32(const float* x, int64_t T, const float* rirs,
  * [P[s]][C][L] (P[s] == 1: a static source, its one filter applied with coefficient 1; P[s] >= 2: a moving source with HOST segment
  * lengths seg_len[s][P[s]-1], sum = T, as in ss_convolve_moving_seg_f32), optional device scalar divisor[s] (deferred peak
  * normalisation as in ss_convolve_moving_seg_div_f32; the array or an entry may be NULL), output y[s][C][T].  The pointer ARRAYS are host
- * arrays of DEVICE pointers (SS_FLAG_DEVICE_PTR required); C < 65536, L > 4096, T < 2^30 (the assembly engine's shapes).  Results are
+ * arrays of DEVICE pointers (SS_FLAG_DEVICE_PTR required); C < 65536, L > 128, T < 2^30 (the assembly engine's shapes).  Results are
  * bit-identical to the separate calls. */
 int ss_convolve_scene_f32(int32_t nsrc, const float* const* x, int64_t T, const float* const* rirs, const int32_t* P, int32_t C, int32_t L,
                           const int64_t* const* seg_len, const float* const* divisor, float* const* y, uint32_t flags, void* stream);

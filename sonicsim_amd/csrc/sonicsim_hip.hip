@@ -3041,8 +3041,8 @@ int render_scene(int nsrc, const float* const* xs, int64_t T, const float* const
     if (nsrc < 1 || nsrc > 8) return fail(SS_EINVAL, "a scene launch takes 1..8 sources (got %d)", nsrc);
     if (!(flags & SS_FLAG_DEVICE_PTR)) return fail(SS_EINVAL, "the scene launch takes device pointers (SS_FLAG_DEVICE_PTR)");
     if (T < 1 || C < 1 || C > 65535 || L < 1) return fail(SS_EINVAL, "bad shape: T=%lld C=%d L=%d", (long long)T, C, L);
-    if (!(T < ((int64_t)1 << 30) && (int64_t)L * 4 < ((int64_t)1 << 31) && L > 2 * B))
-        return fail(SS_EINVAL, "the scene launch exists for the assembly engine's shapes (L > %d, T < 2^30): T=%lld L=%d", 2 * B, (long long)T, L);
+    if (!(T < ((int64_t)1 << 30) && (int64_t)L * 4 < ((int64_t)1 << 31) && L > 128))
+        return fail(SS_EINVAL, "the scene launch exists for the assembly engine's shapes (L > 128, T < 2^30): T=%lld L=%d", (long long)T, L);
     if (!xs || !banks || !Ps || !ys) return fail(SS_EINVAL, "NULL argument");
     for (int s = 0; s < nsrc; ++s) {
         if (!xs[s] || !banks[s] || !ys[s] || Ps[s] < 1) return fail(SS_EINVAL, "source %d: NULL pointer or P < 1", s);

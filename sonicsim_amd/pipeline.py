@@ -170,7 +170,7 @@ class SceneRenderer:
     def prefetch(self, spec: SceneSpec, seed: int):
         """Enqueue the provider of (spec, seed) on the side stream, behind everything enqueued so far on the current stream."""
         import torch
-        if not (self.one_launch and spec.L > 4096):
+        if not (self.one_launch and spec.L > 128):
             return
         if self._k1_stream is None:
             self._k1_stream = torch.cuda.Stream(device=self.device)
@@ -197,7 +197,7 @@ class SceneRenderer:
         it writes the scene's metadata (``SonicSim_audio.lufs_gains_from_result``); a scene generator that pipelines scenes wants this.
         next_scene = (spec, seed) of the scene rendered next: its provider runs on the side stream beside this scene's loudness / mix."""
         import torch
-        if self.one_launch and spec.L > 4096:
+        if self.one_launch and spec.L > 128:
             # the provider first (five K1 launches, or the prefetched set), then ALL five renders in one persistent launch (ss_convolve_scene_f32)
             cur = torch.cuda.current_stream(self.device)
             if self._ready is not None and self._ready[0][0] is spec and self._ready[0][1] == int(seed):

@@ -30,7 +30,7 @@ def test_scene_launch_is_bit_identical_to_separate_renders(gpu, static_lists):
     ops.set_task_queue(not static_lists)
     try:
         for (T, Ps, C, L, seed) in ((150000, (9, 14, 6, 1, 1), 3, 9000, 1), (70000, (1, 5), 2, 20000, 2), (200000, (11,), 4, 12000, 3),
-                                    (90000, (1, 1, 1), 8, 8200, 4)):
+                                    (90000, (1, 1, 1), 8, 8200, 4), (60000, (7, 1, 3), 2, 3000, 5), (40000, (1, 12), 3, 4096, 6), (30000, (4, 1), 1, 300, 7)):
             xs, banks, segs, peaks = _inputs(gpu, T, Ps, C, L, seed)
             want = []
             for x, b, sg, pk in zip(xs, banks, segs, peaks):
@@ -55,7 +55,7 @@ def test_scene_launch_argument_checks(gpu):
     with pytest.raises(ValueError):
         ops.convolve_scene(xs, banks, [segs[0] + 1, None])                            # sum != T
     with pytest.raises(ValueError):
-        ops.convolve_scene(xs, [banks[0][:, :, :3000], banks[1][:, :, :3000]], segs)  # filters too short for the assembly engine
+        ops.convolve_scene(xs, [banks[0][:, :, :100].contiguous(), banks[1][:, :, :100].contiguous()], segs)  # filters too short for the transform engines (L <= 128)
     with pytest.raises(ValueError):
         ops.convolve_scene(xs * 5, banks * 5, segs * 5)                               # more than 8 sources
 
